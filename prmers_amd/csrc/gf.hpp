@@ -1,0 +1,159 @@
+// GF(P), P = 2^64 - 2^32 + 1 (Goldilocks) -- host + gfx950 device arithmetic.
+//
+// Written from scratch for CDNA4: there is no 64x64->128 multiplier on the VALU, so mul() is
+// four 32x32+64 multiply-adds (v_mad_u64_u32) followed by the 2^64 = 2^32-1, 2^96 = -1 folding.
+// Field definition follows the reference (include/marin/arith.h:24-72, kernels/marin.cl:112-148):
+// same prime, same generator 7, sqrt(-1) = 2^48.  Everything here is canonical (inputs and
+// outputs in [0, P)) unless a function says "lazy".
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GF_HD __host__ __device__ __forceinline__
+#else
+#define GF_HD static inline
+#endif
+
+namespace gf {
+
+constexpr uint64_t P = 0xffffffff00000001ull;
+constexpr uint64_t EPS = 0xffffffffull;  // 2^64 mod P = 2^32 - 1
+
+GF_HD uint64_t add(uint64_t a, uint64_t b) {
+  uint64_t s = a + b;
+  // true sum < 2P.  Subtract P (== add EPS mod 2^64) when the 65-bit sum is >= P.
+  bool ge = (s < a) | (s >= P);
+  return s + (ge ? EPS : 0ull);
+}
+
+GF_HD uint64_t sub(uint64_t a, uint64_t b) {
+  uint64_t d = a - b;
+  return d - ((a < b) ? EPS : 0ull);
+}
+
+GF_HD uint64_t neg(uint64_t a) { return a ? P - a : 0ull; }
+
+GF_HD uint64_t dbl(uint64_t a) { return add(a, a); }
+
+// (hi:lo) mod P for hi:lo < P^2  (hi = hh*2^32 + hl):  lo + hl*(2^32-1) - hh.
+GF_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
+  uint32_t hh = (uint32_t)(hi >> 32), hl = (uint32_t)hi;
+  // s = hl*(2^32-1) - hh + (2^32-1)  in [0, P): never wraps.
+  uint64_t s = (((uint64_t)hl << 32) | (uint32_t)(~hh)) - hl;
+  uint64_t r = s + lo;
+  // carry: r + 2^64 == X + EPS  =>  r == X (mod P) because 2^64 == EPS;  r < s < P.
+  // no carry: r == X + EPS: remove EPS, adding P back if that borrows.
+  if (r >= s) {
+    uint64_t t = r - EPS;
+    r = (r < EPS) ? t - EPS : t;
+  }
+  return r;
+}
+
+GF_HD void mul64x64(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+  uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+  uint64_t t0 = (uint64_t)a0 * b0;
+  uint64_t t1 = (uint64_t)a0 * b1 + (t0 >> 32);
+  uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t1;
+  uint64_t t3 = (uint64_t)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+  lo = (t2 << 32) | (uint32_t)t0;
+  hi = t3;
+#else
+  unsigned __int128 t = (unsigned __int128)a * b;
+  lo = (uint64_t)t;
+  hi = (uint64_t)(t >> 64);
+#endif
+}
+
+GF_HD uint64_t mul(uint64_t a, uint64_t b) {
+  uint64_t lo, hi;
+  mul64x64(a, b, lo, hi);
+  return reduce128(lo, hi);
+}
+
+GF_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+
+// a * b for a 32-bit b (digit * weight, small constants): two multiply-adds.
+GF_HD uint64_t mul_u32(uint64_t a, uint32_t b) {
+  uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+  uint64_t t0 = (uint64_t)a0 * b;
+  uint64_t t1 = (uint64_t)a1 * b + (t0 >> 32);
+  uint64_t lo = (t1 << 32) | (uint32_t)t0;
+  uint64_t hi = t1 >> 32;  // < 2^32: hh = 0
+  // lo + hi*(2^32-1)
+  uint64_t s = (hi << 32) - hi;  // < P
+  return add(lo >= P ? lo - P : lo, s);
+}
+
+// a * 2^s for 0 <= s < 192 (2 is a primitive 192nd root of unity, 2^96 = -1).
+// With s a compile-time constant after inlining this is shifts and a few add/sub.
+GF_HD uint64_t mul_pow2(uint64_t a, unsigned s) {
+  bool negate = false;
+  if (s >= 96) { s -= 96; negate = true; }
+  uint64_t r;
+  if (s == 0) {
+    r = a;
+  } else if (s < 32) {
+    // a*2^s = hi*2^64 + lo, hi < 2^32
+    uint64_t lo = a << s, hi = a >> (64 - s);
+    uint64_t t = (hi << 32) - hi;  // hi*(2^32-1) < P
+    r = add(lo >= P ? lo - P : lo, t);
+  } else if (s == 32) {
+    // a = ah*2^32 + al:  a*2^32 = ah*2^64 + al*2^32 = ah*(2^32-1) + al*2^32
+    uint64_t ah = a >> 32, al = a & 0xffffffffull;
+    uint64_t t = (ah << 32) - ah;
+    uint64_t u = al << 32;
+    r = add(u >= P ? u - P : u, t);
+  } else if (s < 64) {
+    // a*2^s = top*2^96 + mid*2^64 + lo  with lo = a << s (64 bits), mid:32 bits, top: s-32 bits
+    unsigned k = s - 32;                       // 0 < k < 32
+    uint64_t lo = a << s;                      // (a << s) mod 2^64
+    uint64_t h = a >> (64 - s);                // bits above 2^64: < 2^s
+    uint64_t mid = h & 0xffffffffull, top = h >> 32;  // top < 2^k
+    (void)k;
+    uint64_t t = (mid << 32) - mid;            // mid*(2^32-1)
+    r = add(lo >= P ? lo - P : lo, t);
+    r = sub(r, top);                           // 2^96 = -1
+  } else if (s == 64) {
+    // a*2^64 = ah*2^96 + al*2^64 = -ah + al*(2^32-1)
+    uint64_t ah = a >> 32, al = a & 0xffffffffull;
+    r = sub((al << 32) - al, ah);
+  } else {
+    // 64 < s < 96: a*2^s = (a*2^(s-64)) * 2^64; a*2^(s-64) = hi2*2^64 + lo2 (hi2 < 2^32)
+    unsigned k = s - 64;                       // 0 < k < 32
+    uint64_t lo2 = a << k, hi2 = a >> (64 - k);
+    // lo2*2^64 = l1*2^96 + l0*2^64 = -l1 + l0*(2^32-1);  hi2*2^128 = hi2 * 2^32 * 2^96 = -(hi2<<32)
+    uint64_t l1 = lo2 >> 32, l0 = lo2 & 0xffffffffull;
+    r = sub((l0 << 32) - l0, l1);
+    r = sub(r, hi2 << 32);                     // hi2<<32 < 2^64-2^32 < P
+  }
+  return negate ? neg(r) : r;
+}
+
+// sqrt(-1) = 2^48
+GF_HD uint64_t muli(uint64_t a) { return mul_pow2(a, 48); }
+
+GF_HD uint64_t half(uint64_t a) { return (a & 1) ? (a >> 1) + ((P + 1) >> 1) : (a >> 1); }
+
+GF_HD uint64_t pow(uint64_t a, uint64_t e) {
+  uint64_t r = 1;
+  while (e) {
+    if (e & 1) r = mul(r, a);
+    a = mul(a, a);
+    e >>= 1;
+  }
+  return r;
+}
+
+GF_HD uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+
+// primitive n-th root of unity, n | P-1 (generator 7: arith.h:72)
+GF_HD uint64_t root_of_unity(uint64_t n) { return pow(7, (P - 1) / n); }
+
+// n-th root of two, n | (P-1)/192 (ibdwt.h:116: 554^((P-1)/192) = 2)
+GF_HD uint64_t root_of_two(uint64_t n) { return pow(554, (P - 1) / 192 / n); }
+
+}  // namespace gf

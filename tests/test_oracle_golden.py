@@ -1,0 +1,249 @@
+"""Pin the CPU oracle: reference known answers, the reference's own host headers (oracle/_ref) and
+plain big-integer arithmetic.  No GPU."""
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import orc
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+HAVE_REF = os.path.exists(orc.REF_HOST)
+
+
+def prp_run(p, check_at=None):
+    """3^(2^p) mod Mp through the oracle engine (RunPrpOrLlMarin.cpp:293-321).  Returns the engine."""
+    o = orc.Oracle(p, 2)
+    o.set(0, 3)
+    seen = {}
+    for it in range(1, p + 1):
+        o.square_mul(0)
+        if check_at and it in check_at:
+            seen[it] = o.res64(0)
+    return o, seen
+
+
+def test_field_matches_python(oracle_lib):
+    P = 2**64 - 2**32 + 1
+    rng = np.random.default_rng(1)
+    vals = [0, 1, 2, P - 1, P - 2, 2**32, 2**32 - 1, 2**63, 0xFFFFFFFF00000000] + [int(x) % P for x in rng.integers(0, 2**63, 200, dtype=np.uint64) * 2]
+    for a in vals:
+        for b in vals[:24]:
+            assert oracle_lib.orc_mod_add(a, b) == (a + b) % P
+            assert oracle_lib.orc_mod_sub(a, b) == (a - b) % P
+            assert oracle_lib.orc_mod_mul(a, b) == (a * b) % P
+    assert oracle_lib.orc_mod_pow(7, P - 1) == 1
+    assert oracle_lib.orc_mod_pow(554, (P - 1) // 192) == 2      # ibdwt.h:116
+    assert oracle_lib.orc_mod_pow(2, 96) == P - 1
+    assert oracle_lib.orc_mod_mul(oracle_lib.orc_mod_invert(12345), 12345) == 1
+
+
+@pytest.mark.parametrize("p,n", [(31, 4), (127, 8), (9815459, 1 << 19),
+                                 (136279841, 1 << 23), (205271257, 5 << 21)])
+def test_transform_size_survey_values(oracle_lib, p, n):
+    # sizes printed by a probe built on the reference's ibdwt.h
+    assert oracle_lib.orc_transform_size(p) == n
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("p", [31, 89, 127, 521, 1279, 3001, 9941, 100003, 1000003, 2500007])
+def test_tables_match_reference_headers(p):
+    """widths / weights / inverse weights equal what the reference's ibdwt.h computes."""
+    o = orc.Oracle(p, 1)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "t.bin")
+        subprocess.check_call([orc.REF_HOST, "tables", str(p), out])
+        raw = open(out, "rb").read()
+    n = int(np.frombuffer(raw[:8], dtype=np.uint64)[0])
+    assert n == o.n
+    width = np.frombuffer(raw[8:8 + n], dtype=np.uint8)
+    w = np.frombuffer(raw[8 + n:8 + n + 8 * n], dtype=np.uint64)
+    wi = np.frombuffer(raw[8 + n + 8 * n:], dtype=np.uint64)
+    ow, owi = o.weights()
+    assert np.array_equal(width, o.widths())
+    assert np.array_equal(w, ow)
+    assert np.array_equal(wi, owi)
+    assert int(width.astype(np.int64).sum()) == p
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built (reference tree absent)")
+def test_transform_size_matches_reference_headers(oracle_lib):
+    rng = np.random.default_rng(7)
+    ps = [3, 5, 31, 61, 89, 127, 1279, 86243, 9815459, 57885161, 136279841, 205271257, 600000001, 2147483647] + \
+        [int(x) for x in rng.integers(100, 2**31, 40)]
+    for p in ps:
+        ref = int(subprocess.check_output([orc.REF_HOST, "size", str(p)]).split()[0])
+        assert oracle_lib.orc_transform_size(p) == ref, p
+
+
+@pytest.mark.parametrize("p", [31, 61, 89, 107, 127, 521, 607, 1279])
+def test_prime_exponents_every_iteration_vs_bigint(p):
+    """x_{k+1} = x_k^2 mod Mp for every k, canonical words against Python integers."""
+    Mp = (1 << p) - 1
+    o = orc.Oracle(p, 1)
+    o.set(0, 3)
+    x = 3
+    for _ in range(p):
+        o.square_mul(0)
+        x = x * x % Mp
+        assert o.value(0) == x
+    d = o.digits(0)
+    assert orc.lib().orc_digits_equal_to(d.ctypes.data, o.n, 9) == 1    # RunPrpOrLlMarin.cpp:452
+
+
+@pytest.mark.parametrize("p", GOLD["composite_exponents"])
+def test_composite_exponents(p):
+    o, _ = prp_run(p)
+    d = o.digits(0)
+    assert orc.lib().orc_digits_equal_to(d.ctypes.data, o.n, 9) == 0
+    x = 3
+    for _ in range(p):
+        x = orc.mers_reduce(x * x, p)
+    assert o.value(0) == x
+
+
+@pytest.mark.slow
+def test_m11213_intermediate_res64():
+    want = {int(k): v for k, v in GOLD["m11213_intermediate_res64"].items() if k != "src"}
+    o, seen = prp_run(11213, set(want))
+    for k, hexv in want.items():
+        assert "%016X" % seen[k] == hexv, k
+    d = o.digits(0)
+    assert orc.lib().orc_digits_equal_to(d.ctypes.data, o.n, 9) == 1
+    r64, r2048 = orc.prp_type1_hex(d, 11213)
+    assert r64 == GOLD["m11213_final"]["res64"]
+    assert r2048 == "0" * 511 + "1"
+
+
+@pytest.mark.slow
+def test_m100003_res64_res2048():
+    p = 100003
+    o, _ = prp_run(p)
+    d = o.digits(0)
+    r64, r2048 = orc.prp_type1_hex(d, p)
+    assert r64 == GOLD["m100003"]["res64"]
+    assert r2048 == GOLD["m100003"]["res2048"]
+    # independent: type-1 residue = (final residue) / 9 mod Mp, with Python integers
+    Mp = (1 << p) - 1
+    t1 = o.value(0) * pow(9, -1, Mp) % Mp
+    assert "%016X" % (t1 & (2**64 - 1)) == r64
+    assert "%0512x" % (t1 & (2**2048 - 1)) == r2048
+
+
+def test_reg_adapter_expectations():
+    """Op-level contract of tests/test_aevum_reg_adapter.cpp:32-86 on the oracle engine."""
+    g = GOLD["reg_adapter"]
+    p = g["p"]
+    M = (1 << p) - 1
+    o = orc.Oracle(p, 8)
+    o.set(0, 5); o.set(1, 7)
+    o.set_multiplicand(2, 1)
+    o.mul(0, 2)
+    assert o.value(0) == g["mul"]
+    o.square_mul(0, 3)
+    assert o.value(0) == g["square_mul3"]
+    o.add(0, 1); o.sub_reg(0, 1); o.sub(0, 2)
+    assert o.value(0) == g["addsub"]
+    o.set_value(3, M + 123)
+    assert o.value(3) == g["set_mpz"]
+    # pow (engine.h:160-170)
+    o.set(5, g["pow_base"]); o.set_multiplicand(5, 5); o.set(6, 1)
+    e = g["pow_exp"]
+    for i in range(e.bit_length() - 1, -1, -1):
+        o.square_mul(6)
+        if (e >> i) & 1:
+            o.mul(6, 5)
+    assert o.value(6) == pow(g["pow_base"], e, M)
+    assert o.res64(3) == 123
+
+
+@pytest.mark.parametrize("p", [127, 1279, 9941, 3997])
+def test_ops_random_vs_bigint(p):
+    """mul / square_mul(a) / add / sub_reg / sub on random residues against Python integers."""
+    M = (1 << p) - 1
+    rng = np.random.default_rng(p)
+    o = orc.Oracle(p, 6)
+    for _ in range(6):
+        x = int.from_bytes(rng.bytes((p + 7) // 8), "little") % M
+        y = int.from_bytes(rng.bytes((p + 7) // 8), "little") % M
+        a = int(rng.integers(1, 1000))
+        o.set_value(0, x); o.set_value(1, y)
+        assert o.value(0) == x and o.value(1) == y
+        o.set_multiplicand(2, 1)
+        o.mul(0, 2, a)
+        assert o.value(0) == x * y * a % M
+        o.square_mul(0, a)
+        z = (x * y * a) ** 2 * a % M
+        assert o.value(0) == z
+        o.add(0, 1)
+        assert o.value(0) == (z + y) % M
+        o.sub_reg(0, 1); o.sub_reg(0, 1)
+        assert o.value(0) == (z - y) % M
+        o.sub(0, 2)
+        assert o.value(0) == (z - y - 2) % M
+    # LL: x -> x^2 - 2 from 4 (RunPrpOrLlMarin.cpp:229,321-324)
+    o.set(0, 4)
+    s = 4
+    for _ in range(20):
+        o.square_mul(0); o.sub(0, 2)
+        s = (s * s - 2) % M
+        assert o.value(0) == s
+
+
+@pytest.mark.parametrize("p", [933, 1801, 3997, 6997, 13967, 102701])
+def test_radix5_sizes(oracle_lib, p):
+    """exponents whose transform length is 5*2^k (ibdwt.h:32-42)."""
+    n = oracle_lib.orc_transform_size(p)
+    assert n % 5 == 0
+    M = (1 << p) - 1
+    o = orc.Oracle(p, 2)
+    o.set(0, 3)
+    x = 3
+    for _ in range(40):
+        o.square_mul(0)
+        x = x * x % M
+    assert o.value(0) == x
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("p", [127, 9941, 100003])
+def test_digit_formatting_matches_reference_headers(p):
+    """res64 / equal_to / get_mpz / pack_words / div9 / hex: oracle vs the reference's own inline code."""
+    M = (1 << p) - 1
+    rng = np.random.default_rng(p)
+    o = orc.Oracle(p, 2)
+    cases = [9, 0, M, 3, int.from_bytes(rng.bytes((p + 7) // 8), "little") % M]
+    for v in cases:
+        if v == M:
+            d = o.widths().astype(np.uint64)
+            d = ((np.uint64(1) << d) - np.uint64(1)) | (d << np.uint64(32))
+        else:
+            o.set_value(0, v)
+            d = o.digits(0)
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "d.bin")
+            d.tofile(f)
+            out = subprocess.check_output([orc.REF_HOST, "digits", str(p), f]).decode().split()
+        res64, eq9, eqMp, zhex, r64d9, r2048d9, r64raw = out
+        L = orc.lib()
+        assert int(res64, 16) == L.orc_digits_res64(d.ctypes.data, o.n)
+        assert int(eq9) == L.orc_digits_equal_to(d.ctypes.data, o.n, 9)
+        assert int(eqMp) == L.orc_digits_equal_to_Mp(d.ctypes.data, o.n)
+        assert int(zhex, 16) == (0 if v == M else v)
+        a64, a2048 = orc.prp_type1_hex(d, p)
+        assert (a64, a2048) == (r64d9, r2048d9)
+        w = orc.pack_words(d, p)
+        assert "%016X" % (orc.words_to_int(w) & (2**64 - 1)) == r64raw
+        if v != M:
+            # reference set_mpz -> digits equals the oracle's set_words
+            with tempfile.TemporaryDirectory() as td:
+                f = os.path.join(td, "o.bin")
+                subprocess.check_call([orc.REF_HOST, "setmpz", str(p), "%x" % (v + M), f])
+                dref = np.fromfile(f, dtype=np.uint64)
+            # engine::set_mpz truncates bit-wise (no reduction); compare for v < Mp only via value
+            o.set_value(1, v)
+            assert orc.digits_to_int(o.digits(1)) == v
+            assert dref.size == o.n
