@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Marin-path modular squaring x <- x^2 mod 2^p-1 at p ~ 136M on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one square_mul on every rank's own exponent (independent residues, one exponent per GPU,
+no data-path collective: SURVEY.md 8e).  The residue vector is resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- dominant kernel: algorithmic bytes per launch (16*n: one read+write sweep of the
+                  8-byte residue vector, SURVEY.md 8d: 48*n per squaring = 3 sweeps) / its average
+                  duration from HIP events on the engine's stream, against the 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference has no CPU
+                  implementation of this path) timed on this box's host cores, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[2] / metric: p = 136279841 (n = 2^23); one distinct prime exponent of the same
+# transform size per GPU for the multi-GPU runs (worktodo-style sharding, configs[4])
+EXPONENTS = [136279841, 136279879, 136279901, 136279919, 136279933, 136279967, 136279981, 136279987]
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def seeded_digits(p, n, seed):
+    """digits uniform in [0, 2^width): distribution-equivalent to a mid-run residue."""
+    import numpy as np
+    j = np.arange(n + 1, dtype=np.uint64)
+    ceil = (j * np.uint64(p) + np.uint64(n - 1)) // np.uint64(n)
+    width = (ceil[1:] - ceil[:-1]).astype(np.uint64)
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << width) - np.uint64(1))
+    return d | (width << np.uint64(32))
+
+
+def cpu_baseline(p, sample_iters=6):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc   # the oracle is the checker / CPU baseline only (never on the product path)
+    o = orc.Oracle(p, 1)
+    o.set_digits(0, seeded_digits(p, o.n, 1))
+    o.square_mul(0)   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(sample_iters):
+        o.square_mul(0)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_iters / dt, 4), "unit": "iter/s", "ms_per_iter": round(1e3 * dt / sample_iters, 2),
+            "cores": int(orc.lib().orc_threads()), "kind": "port",
+            "sample": "%d squarings at p=%d (n=%d) by oracle/oracle.c, OpenMP" % (sample_iters, p, o.n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--exponent", type=int, default=0, help="override the exponent (testing)")
+    ap.add_argument("--plan", type=str, default=None, help="plan override, e.g. m2=4096,c=4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from prmers_amd import Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    p = args.exponent or EXPONENTS[rank % len(EXPONENTS)]
+    eng = Engine(p, 2, device=local_rank, plan=args.plan)
+    eng.set_digits(0, seeded_digits(p, eng.n, 1000 + rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    eng.time_square_mul(0, max(1, args.warmup))
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev_ms, _ = eng.time_square_mul(0, args.steps)      # K squarings enqueued back to back, HIP events around them
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+
+    status = torch.tensor([1, 0, args.steps], dtype=torch.int64, device="cuda")   # ok, gerbicz errors, iterations
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(status, op=dist.ReduceOp.SUM)   # the only cross-GPU traffic: a 24-byte status word
+    elapsed = float(tmax.item())
+
+    # second, instrumented pass of the same loop: per-kernel durations from event pairs on the engine stream
+    _, kern = eng.time_square_mul(0, min(args.steps, 64), per_kernel=True)
+    if rank == 0:
+        n = eng.n
+        chain = {k: v for k, v in kern.items() if k != "k_sub_small"}
+        dom = max(chain, key=chain.get)
+        dom_ms = chain[dom]
+        sweep_bytes = 16 * n
+        achieved = sweep_bytes / (dom_ms * 1e-3) / 1e9
+        ms_per_step = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "PRP squaring throughput at p~136M (Marin IBDWT, one exponent per GPU)",
+            "value": round(world * args.steps / elapsed, 3),
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 (GF(2^64-2^32+1))",
+            "data": "synthetic",
+            "config": {"workload": "square_mul x<-x^2 mod 2^p-1, p=%d, n=%d words" % (p, n),
+                       "plan": __import__("prmers_amd").resolve_plan(p, args.plan),
+                       "exponents": EXPONENTS[:world] if not args.exponent else [p],
+                       "parallelism": "replicas: one exponent per GPU, no data-path collective"},
+            "event_ms_per_step": round(ev_ms / args.steps, 5),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": sweep_bytes,
+                         "kernel_ms": {k: round(v, 5) for k, v in kern.items()},
+                         "iteration": {"algorithmic_bytes": 48 * n,
+                                       "achieved": round(48 * n / (ms_per_step * 1e-3) / 1e9, 1),
+                                       "frac": round(48 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+/* libmi355_engine.so -- C ABI of the MI355X-native Goldilocks IBDWT engine.
+ *
+ * Drop-in boundary for the reference's Marin backend (cherubrock-seb/PrMers).  The shapes are the
+ * reference's own engine-plugin ABI (third_party/aevum/src/EngineApi.h:28-59, loaded with dlopen by
+ * src/aevum/EngineAevum.cpp:225-243) under the prefix mi355_engine_, so the reference's adapter
+ * pattern binds it unchanged; the C++ adapter that serves `-engine-marin` is include/mi355/engine_hip.h
+ * (hook: src/marin/gpu.cpp:149).
+ *
+ * Conventions (same as the reference ABI, EngineApi.cpp:447-517):
+ *   - int results: 1 = ok, 0 = failure; the message is in mi355_engine_last_error() (thread-local,
+ *     owned by the library).  create() returns NULL on failure.  No exception ever crosses the ABI.
+ *   - registers are indices 0..register_count-1; a register holds a residue mod 2^p-1, or -- after
+ *     prepare(dst, src) -- an opaque multiplicand image only valid as the src of mul()
+ *     (engine.h:52-60, engine_gpu.h:1695-1756).
+ *   - residues cross the boundary as little-endian 32-bit words of the canonical value in
+ *     [0, 2^p-1), word_count = ceil(p/32)  (EngineApi.cpp:210-218), or as IBDWT digits
+ *     value | width << 32 (engine.h:24-25).
+ *   - one engine = one HIP device + one stream; calls are asynchronous, sync() / any read drains the
+ *     stream (engine_gpu.h:1427-1430).  An engine is not thread-safe; engines are independent.
+ *   - there is NO CPU fallback: without a usable HIP device create() fails with a clear message.
+ */
+#ifndef MI355_ENGINE_H
+#define MI355_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#define MI355_ENGINE_API __attribute__((visibility("default")))
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mi355_engine_handle;
+
+/* ---- the 19 shapes of the reference plugin ABI (EngineApi.h:28-59) ---- */
+MI355_ENGINE_API const char* mi355_engine_version(void);                                    /* :28 */
+MI355_ENGINE_API const char* mi355_engine_last_error(void);                                 /* :29 */
+/* transform plan for an exponent as text ("marin-hip:n=..:m1=..:m2=..:c=.."); needs no GPU.   :30-34 */
+MI355_ENGINE_API int mi355_engine_resolve_fft(uint32_t exponent, const char* fft_spec, char* output, size_t output_size);
+/* engine::create_gpu(p, reg_count, device, verbose) (engine.h:301, src/marin/gpu.cpp:52).     :36-42
+   fft_spec: NULL/"" = automatic, or "m2=<rows>,c=<columns per tile>"; tune_dir is ignored. */
+MI355_ENGINE_API mi355_engine_handle mi355_engine_create(uint32_t exponent, size_t register_count, uint32_t device,
+                                                         int verbose, const char* fft_spec, const char* tune_dir);
+MI355_ENGINE_API void mi355_engine_destroy(mi355_engine_handle handle);                      /* :44 */
+MI355_ENGINE_API size_t mi355_engine_transform_size(mi355_engine_handle handle);            /* engine::get_size, engine.h:40 */
+MI355_ENGINE_API size_t mi355_engine_word_count(mi355_engine_handle handle);                /* :46 */
+MI355_ENGINE_API int mi355_engine_sync(mi355_engine_handle handle);                         /* engine::sync, engine.h:45 */
+
+MI355_ENGINE_API int mi355_engine_set_u32(mi355_engine_handle handle, size_t dst, uint32_t value);   /* engine::set, engine.h:47 */
+MI355_ENGINE_API int mi355_engine_set_words(mi355_engine_handle handle, size_t dst, const uint32_t* words, size_t count); /* set_mpz, engine.h:206 */
+MI355_ENGINE_API int mi355_engine_get_words(mi355_engine_handle handle, size_t src, uint32_t* words, size_t count);       /* get_mpz, engine.h:173 */
+MI355_ENGINE_API int mi355_engine_copy(mi355_engine_handle handle, size_t dst, size_t src);          /* engine::copy, engine.h:49 */
+MI355_ENGINE_API int mi355_engine_prepare(mi355_engine_handle handle, size_t dst, size_t src);       /* set_multiplicand, engine.h:53 */
+MI355_ENGINE_API int mi355_engine_square_mul(mi355_engine_handle handle, size_t reg, uint32_t factor);      /* engine.h:51 */
+MI355_ENGINE_API int mi355_engine_mul(mi355_engine_handle handle, size_t dst, size_t src, uint32_t factor); /* engine.h:60 */
+MI355_ENGINE_API int mi355_engine_add(mi355_engine_handle handle, size_t dst, size_t src);           /* engine.h:64 */
+MI355_ENGINE_API int mi355_engine_sub_reg(mi355_engine_handle handle, size_t dst, size_t src);       /* engine.h:71 */
+MI355_ENGINE_API int mi355_engine_sub_u32(mi355_engine_handle handle, size_t dst, uint32_t value);   /* engine::sub, engine.h:62 */
+MI355_ENGINE_API int mi355_engine_equal(mi355_engine_handle handle, size_t lhs, size_t rhs, int* equal_out); /* is_equal, engine.h:148 */
+
+/* ---- rest of the engine surface the Marin callers use ---- */
+/* engine::get / engine::set(Reg, uint64*) (engine.h:24-25): n digits, value | width << 32, strongly
+   carried (engine_gpu.h:1534-1561).  count must equal transform_size(). */
+MI355_ENGINE_API int mi355_engine_get_digits(mi355_engine_handle handle, size_t src, uint64_t* digits, size_t count);
+MI355_ENGINE_API int mi355_engine_set_digits(mi355_engine_handle handle, size_t dst, const uint64_t* digits, size_t count);
+/* engine::digit::res64 (engine.h:257-269) */
+MI355_ENGINE_API int mi355_engine_res64(mi355_engine_handle handle, size_t src, uint64_t* res64_out);
+/* raw register images: get_register_data_size / get_data / set_data / *checkpoint (engine.h:134-146).
+   Images are implementation-defined (as in the reference); sizes must match exactly or the call fails. */
+MI355_ENGINE_API size_t mi355_engine_register_data_size(mi355_engine_handle handle);
+MI355_ENGINE_API int mi355_engine_get_data(mi355_engine_handle handle, size_t src, void* data, size_t size);
+MI355_ENGINE_API int mi355_engine_set_data(mi355_engine_handle handle, size_t dst, const void* data, size_t size);
+MI355_ENGINE_API size_t mi355_engine_checkpoint_size(mi355_engine_handle handle);
+MI355_ENGINE_API int mi355_engine_get_checkpoint(mi355_engine_handle handle, void* data, size_t size);
+MI355_ENGINE_API int mi355_engine_set_checkpoint(mi355_engine_handle handle, const void* data, size_t size);
+
+/* ---- measurement hooks (bench.py; the reference's profiling map, ocl.h:238-247,657-675) ---- */
+/* `iters` back-to-back square_mul(reg, factor) [+ sub_u32(sub) when sub != 0: the LL step x^2-2]
+   timed with HIP events on the engine's own stream.  total_ms = wall of the whole batch.
+   kernel_ms[k] (k < kernel_count, may be NULL) = average duration of kernel k of the chain
+   (names from mi355_engine_kernel_name), from per-launch event pairs in a second instrumented batch. */
+MI355_ENGINE_API int mi355_engine_time_square_mul(mi355_engine_handle handle, size_t reg, uint32_t factor, uint32_t sub,
+                                                  size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count);
+MI355_ENGINE_API size_t mi355_engine_kernel_count(mi355_engine_handle handle);
+MI355_ENGINE_API const char* mi355_engine_kernel_name(mi355_engine_handle handle, size_t k);
+/* algorithmic bytes one squaring moves (48 * n) */
+MI355_ENGINE_API size_t mi355_engine_algorithmic_bytes(mi355_engine_handle handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

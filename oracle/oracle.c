@@ -181,6 +181,13 @@ int orc_threads(void) {
   return 1;
 #endif
 }
+void orc_set_threads(int t) {
+#ifdef _OPENMP
+  if (t > 0) omp_set_num_threads(t);
+#else
+  (void)t;
+#endif
+}
 
 /* ---- length-m transform of one plane (m = {1,5} * 2^k).  Output order: block k1 (0..r5-1),
    position pos holds frequency k1 + r5 * bitrev(pos). ---- */

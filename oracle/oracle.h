@@ -42,6 +42,7 @@ uint32_t orc_exponent(const orc_ctx* c);
 void orc_widths(const orc_ctx* c, uint8_t* out);         /* n digit widths, ibdwt.h:127-132 */
 void orc_weights(const orc_ctx* c, uint64_t* w, uint64_t* winv); /* natural digit order, ibdwt.h:134-143 */
 int orc_threads(void);                                   /* OpenMP threads used by the transforms */
+void orc_set_threads(int t);
 
 /* engine operations (engine.h:47-71; engine_gpu.h:1432-1630,1695-1884,2085-2098) */
 void orc_set_u32(orc_ctx* c, size_t dst, uint32_t a);

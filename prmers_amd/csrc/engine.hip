@@ -1,0 +1,407 @@
+// Engine implementation: buffers, host-side digit I/O, kernel sequencing.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace mi355 {
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " in " #expr); \
+  } while (0)
+
+template <class T>
+static const T* upload(unsigned char*& cursor, unsigned char* base, const std::vector<T>& v, std::vector<unsigned char>& host) {
+  const size_t off = size_t(cursor - base);
+  std::memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+  const T* p = reinterpret_cast<const T*>(cursor);
+  cursor += (v.size() * sizeof(T) + 255) & ~size_t(255);
+  return p;
+}
+
+Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const char* spec)
+    : pl_(make_plan(p, spec, true)), device_(device), verbose_(verbose), nregs_(reg_count) {
+  if (reg_count == 0) throw std::runtime_error("register_count must be > 0");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
+  if (device < 0 || device >= ndev) throw std::runtime_error("HIP device index out of range");
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+
+  reg_bytes_ = pl_.n * 8;  // digits use the first 4n bytes, a multiplicand image all 8n
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&regs_), nregs_ * reg_bytes_));
+  HIPCHK(hipMemsetAsync(regs_, 0, nregs_ * reg_bytes_, stream_));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&work_), reg_bytes_));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&cbuf_), pl_.runs() * 8));
+  HIPCHK(hipMemsetAsync(cbuf_, 0, pl_.runs() * 8, stream_));
+  kind_.assign(nregs_, kDigits);
+
+  // one allocation for all tables
+  auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+  const size_t total = padded(pl_.SA.size() * 4) + padded(pl_.SB.size() * 4) + padded(pl_.TA.size() * 8) * 2 +
+                       padded(pl_.TB.size() * 8) * 2 + padded(pl_.TWlo.size() * 8) + padded(pl_.TWhi.size() * 8) +
+                       padded(pl_.UT1.size() * 8) + padded(pl_.UT2.size() * 8);
+  HIPCHK(hipMalloc(&tables_, total));
+  std::vector<unsigned char> host(total, 0);
+  unsigned char* base = static_cast<unsigned char*>(tables_);
+  unsigned char* cur = base;
+  dp_.SA = upload(cur, base, pl_.SA, host);
+  dp_.SB = upload(cur, base, pl_.SB, host);
+  dp_.TA = upload(cur, base, pl_.TA, host);
+  dp_.TAi = upload(cur, base, pl_.TAi, host);
+  dp_.TB = upload(cur, base, pl_.TB, host);
+  dp_.TBi = upload(cur, base, pl_.TBi, host);
+  dp_.TWlo = upload(cur, base, pl_.TWlo, host);
+  dp_.TWhi = upload(cur, base, pl_.TWhi, host);
+  dp_.UT1 = upload(cur, base, pl_.UT1, host);
+  dp_.UT2 = upload(cur, base, pl_.UT2, host);
+  HIPCHK(hipMemcpy(tables_, host.data(), total, hipMemcpyHostToDevice));
+
+  dp_.n = uint32_t(pl_.n); dp_.m = uint32_t(pl_.m);
+  dp_.M1 = pl_.M1; dp_.M2 = pl_.M2; dp_.L1 = pl_.L1; dp_.logL1 = pl_.logL1; dp_.logM2 = pl_.logM2;
+  dp_.r5 = pl_.r5; dp_.C = pl_.C; dp_.q = pl_.q; dp_.t = pl_.t; dp_.twh = pl_.twh;
+  dp_.I4 = pl_.I4; dp_.I4inv = pl_.I4inv;
+  for (int i = 0; i < 5; ++i) { dp_.W5[i] = pl_.W5[i]; dp_.W5i[i] = pl_.W5i[i]; }
+  HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
+
+  // digit widths in natural order (ibdwt.h:127-132), s_j = p*j mod n kept incrementally
+  width_.resize(pl_.n);
+  uint64_t s = 0;
+  for (size_t j = 0; j < pl_.n; ++j) {
+    width_[j] = uint8_t(pl_.width_of_s(s));
+    s += pl_.t; if (s >= pl_.n) s -= pl_.n;
+  }
+  HIPCHK(hipStreamSynchronize(stream_));
+  if (verbose_) std::fprintf(stderr, "[mi355] p=%u %s regs=%zu device=%d\n", p, pl_.describe().c_str(), nregs_, device_);
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  if (regs_) (void)hipFree(regs_);
+  if (work_) (void)hipFree(work_);
+  if (cbuf_) (void)hipFree(cbuf_);
+  if (tables_) (void)hipFree(tables_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::check_reg(size_t r) const {
+  if (r >= nregs_) throw std::runtime_error("register index out of range");
+}
+void Engine::need_digits(size_t r, const char* op) const {
+  check_reg(r);
+  if (kind_[r] != kDigits) throw std::runtime_error(std::string(op) + ": register holds a multiplicand image, not a residue");
+}
+
+void Engine::sync() {
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipStreamSynchronize(stream_));
+}
+
+// ---- host digit I/O -------------------------------------------------------------------------
+
+void Engine::write_values(size_t dst, const std::vector<uint32_t>& natural) {
+  stage_.resize(pl_.n);
+  const size_t M2 = pl_.M2, C = pl_.C, M1 = pl_.M1;
+  for (size_t i = 0; i < pl_.m; ++i) {
+    const size_t i1 = i / M2, i2 = i % M2, T = i2 / C, c = i2 % C;
+    const size_t s = ((T * M1 + i1) * C + c) * 2;
+    stage_[s] = natural[2 * i];
+    stage_[s + 1] = natural[2 * i + 1];
+  }
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipMemcpy(digits(dst), stage_.data(), pl_.n * 4, hipMemcpyHostToDevice));
+  kind_[dst] = kDigits;
+}
+
+void Engine::read_values(size_t src, std::vector<uint64_t>& v) {
+  need_digits(src, "get");
+  stage_.resize(pl_.n);
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipMemcpy(stage_.data(), digits(src), pl_.n * 4, hipMemcpyDeviceToHost));
+  v.resize(pl_.n);
+  const size_t M2 = pl_.M2, C = pl_.C, M1 = pl_.M1;
+  for (size_t i = 0; i < pl_.m; ++i) {
+    const size_t i1 = i / M2, i2 = i % M2, T = i2 / C, c = i2 % C;
+    const size_t s = ((T * M1 + i1) * C + c) * 2;
+    v[2 * i] = stage_[s];
+    v[2 * i + 1] = stage_[s + 1];
+  }
+  // strong carry with wrap-around (engine_gpu.h:1543-1557)
+  uint64_t c = 0;
+  for (size_t k = 0; k < pl_.n; ++k) {
+    const uint64_t t = v[k] + c;
+    v[k] = t & ((uint64_t(1) << width_[k]) - 1);
+    c = t >> width_[k];
+  }
+  while (c != 0) {
+    for (size_t k = 0; k < pl_.n; ++k) {
+      const uint64_t t = v[k] + c;
+      v[k] = t & ((uint64_t(1) << width_[k]) - 1);
+      c = t >> width_[k];
+      if (c == 0) break;
+    }
+  }
+}
+
+void Engine::set_u32(size_t dst, uint32_t value) {
+  check_reg(dst);
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipMemsetAsync(digits(dst), 0, pl_.n * 4, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  // spread the constant over the first digits (the reference stores it whole in digit 0,
+  // engine_gpu.h:1444-1449; same value, but never an over-wide digit)
+  uint64_t v = value;
+  for (size_t j = 0; j < pl_.n && v; ++j) {
+    const uint32_t d = uint32_t(v & ((uint64_t(1) << width_[j]) - 1));
+    v >>= width_[j];
+    if (d) HIPCHK(hipMemcpy(digits(dst) + pl_.pos(j), &d, 4, hipMemcpyHostToDevice));
+  }
+  kind_[dst] = kDigits;
+}
+
+void Engine::set_digits(size_t dst, const uint64_t* d, size_t count) {
+  check_reg(dst);
+  if (count != pl_.n) throw std::runtime_error("set_digits: count must equal the transform size");
+  std::vector<uint32_t> nat(pl_.n);
+  for (size_t k = 0; k < pl_.n; ++k) nat[k] = uint32_t(d[k]);
+  write_values(dst, nat);
+}
+
+void Engine::get_digits(size_t src, uint64_t* d, size_t count) {
+  if (count != pl_.n) throw std::runtime_error("get_digits: count must equal the transform size");
+  std::vector<uint64_t> v;
+  read_values(src, v);
+  for (size_t k = 0; k < pl_.n; ++k) d[k] = uint32_t(v[k]) | (uint64_t(width_[k]) << 32);  // engine_gpu.h:1560
+}
+
+uint64_t Engine::res64(size_t src) {
+  std::vector<uint64_t> v;
+  read_values(src, v);
+  uint64_t r64 = 0; unsigned s = 0;   // engine.h:257-269
+  for (size_t k = 0; k < pl_.n; ++k) {
+    r64 += v[k] << s;
+    s += width_[k];
+    if (s >= 64) break;
+  }
+  return r64;
+}
+
+void Engine::get_words(size_t src, uint32_t* w, size_t count) {
+  if (count != word_count()) throw std::runtime_error("get_words: count must equal word_count()");
+  std::vector<uint64_t> v;
+  read_values(src, v);
+  bool all_ones = true;   // 2^p - 1 == 0 (engine.h:188-196)
+  for (size_t k = 0; k < pl_.n && all_ones; ++k) all_ones = (v[k] == (uint64_t(1) << width_[k]) - 1);
+  std::memset(w, 0, count * 4);
+  if (all_ones) return;
+  size_t bit = 0;
+  for (size_t k = 0; k < pl_.n; ++k) {
+    const size_t i = bit / 32, s = bit % 32;
+    const uint64_t x = v[k] << s;
+    w[i] |= uint32_t(x);
+    if ((x >> 32) && i + 1 < count) w[i + 1] |= uint32_t(x >> 32);
+    bit += width_[k];
+  }
+}
+
+void Engine::set_words(size_t dst, const uint32_t* w, size_t count) {
+  check_reg(dst);
+  if (count != word_count()) throw std::runtime_error("set_words: count must equal word_count()");
+  // bits at and above p are folded back (2^p = 1), so any count-word value is accepted
+  std::vector<uint32_t> src(w, w + count);
+  src.push_back(0);
+  const unsigned top = pl_.p % 32;
+  uint64_t fold = 0;
+  if (top) { fold = src[count - 1] >> top; src[count - 1] &= (1u << top) - 1; }
+  for (size_t i = 0; fold && i < count; ++i) {  // add the folded bits at bit 0
+    const uint64_t t = uint64_t(src[i]) + (fold & 0xffffffffu);
+    src[i] = uint32_t(t);
+    fold = (fold >> 32) + (t >> 32);
+  }
+  if (top && (src[count - 1] >> top)) {  // the addition rippled past bit p once more
+    src[count - 1] &= (1u << top) - 1;
+    for (size_t i = 0; i < count; ++i) { if (++src[i] != 0) break; }
+  }
+  std::vector<uint32_t> nat(pl_.n);
+  size_t bit = 0;
+  for (size_t k = 0; k < pl_.n; ++k) {   // engine.h:206-232
+    const size_t i = bit / 32, s = bit % 32;
+    uint64_t u = src[i] >> s;
+    if (s != 0) u |= uint64_t(src[i + 1]) << (32 - s);
+    nat[k] = uint32_t(u & ((uint64_t(1) << width_[k]) - 1));
+    bit += width_[k];
+  }
+  write_values(dst, nat);
+}
+
+bool Engine::equal(size_t lhs, size_t rhs) {
+  std::vector<uint32_t> a(word_count()), b(word_count());
+  get_words(lhs, a.data(), a.size());
+  get_words(rhs, b.data(), b.size());
+  return a == b;
+}
+
+// ---- register operations -------------------------------------------------------------------
+
+void Engine::copy(size_t dst, size_t src) {
+  check_reg(dst); check_reg(src);
+  if (dst == src) return;
+  HIPCHK(hipSetDevice(device_));
+  const size_t bytes = (kind_[src] == kDigits) ? pl_.n * 4 : reg_bytes_;
+  HIPCHK(hipMemcpyAsync(regs_ + dst * reg_bytes_, regs_ + src * reg_bytes_, bytes, hipMemcpyDeviceToDevice, stream_));
+  kind_[dst] = kind_[src];
+}
+
+void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
+  if (ev) HIPCHK(hipEventRecord(ev[0], stream_));
+  HIPCHK(launch_front(dp_, digits(r), work_, stream_));
+  if (ev) HIPCHK(hipEventRecord(ev[1], stream_));
+  HIPCHK(launch_middle(dp_, work_, nullptr, work_, 0, stream_));
+  if (ev) HIPCHK(hipEventRecord(ev[2], stream_));
+  HIPCHK(launch_back(dp_, work_, digits(r), cbuf_, a, stream_));
+  if (ev) HIPCHK(hipEventRecord(ev[3], stream_));
+  HIPCHK(launch_carry_fix(dp_, digits(r), cbuf_, stream_));
+  if (ev) HIPCHK(hipEventRecord(ev[4], stream_));
+}
+
+void Engine::square_mul(size_t r, uint32_t a) {
+  need_digits(r, "square_mul");
+  if (a == 0) throw std::runtime_error("square_mul: factor must be >= 1");
+  HIPCHK(hipSetDevice(device_));
+  square_chain(r, a, nullptr);
+}
+
+void Engine::prepare(size_t dst, size_t src) {
+  need_digits(src, "set_multiplicand");
+  check_reg(dst);
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(launch_front(dp_, digits(src), work_, stream_));
+  HIPCHK(launch_middle(dp_, work_, nullptr, image(dst), 2, stream_));
+  kind_[dst] = kImage;
+}
+
+void Engine::mul(size_t dst, size_t src, uint32_t a) {
+  need_digits(dst, "mul");
+  check_reg(src);
+  if (kind_[src] != kImage) throw std::runtime_error("mul: src must be a multiplicand (set_multiplicand)");
+  if (dst == src) throw std::runtime_error("mul: dst and src must differ");
+  if (a == 0) throw std::runtime_error("mul: factor must be >= 1");
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(launch_front(dp_, digits(dst), work_, stream_));
+  HIPCHK(launch_middle(dp_, work_, image(src), work_, 1, stream_));
+  HIPCHK(launch_back(dp_, work_, digits(dst), cbuf_, a, stream_));
+  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf_, stream_));
+}
+
+void Engine::add(size_t dst, size_t src) {
+  need_digits(dst, "add"); need_digits(src, "add");
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf_, 0, stream_));
+  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf_, stream_));
+}
+
+void Engine::sub_reg(size_t dst, size_t src) {
+  need_digits(dst, "sub_reg"); need_digits(src, "sub_reg");
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf_, 1, stream_));
+  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf_, stream_));
+}
+
+void Engine::sub_u32(size_t r, uint32_t v) {
+  need_digits(r, "sub");
+  if (v == 0) return;
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(launch_sub_small(dp_, digits(r), v, stream_));
+}
+
+// ---- raw images -----------------------------------------------------------------------------
+
+void Engine::get_data(size_t src, void* data, size_t size) {
+  check_reg(src);
+  if (size != register_data_size()) throw std::runtime_error("get_data: size mismatch");
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipMemcpy(data, regs_ + src * reg_bytes_, reg_bytes_, hipMemcpyDeviceToHost));
+  const uint64_t tag = kind_[src];
+  std::memcpy(static_cast<unsigned char*>(data) + reg_bytes_, &tag, 8);
+}
+
+void Engine::set_data(size_t dst, const void* data, size_t size) {
+  check_reg(dst);
+  if (size != register_data_size()) throw std::runtime_error("set_data: size mismatch");
+  uint64_t tag = 0;
+  std::memcpy(&tag, static_cast<const unsigned char*>(data) + reg_bytes_, 8);
+  if (tag > 1) throw std::runtime_error("set_data: not an image written by this engine");
+  HIPCHK(hipSetDevice(device_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipMemcpy(regs_ + dst * reg_bytes_, data, reg_bytes_, hipMemcpyHostToDevice));
+  kind_[dst] = uint8_t(tag);
+}
+
+void Engine::get_checkpoint(void* data, size_t size) {
+  if (size != checkpoint_size()) throw std::runtime_error("get_checkpoint: size mismatch");
+  for (size_t r = 0; r < nregs_; ++r) get_data(r, static_cast<unsigned char*>(data) + r * register_data_size(), register_data_size());
+}
+
+void Engine::set_checkpoint(const void* data, size_t size) {
+  if (size != checkpoint_size()) throw std::runtime_error("set_checkpoint: size mismatch");
+  for (size_t r = 0; r < nregs_; ++r) set_data(r, static_cast<const unsigned char*>(data) + r * register_data_size(), register_data_size());
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+
+const char* Engine::kernel_name(size_t k) {
+  static const char* names[kKernels] = {"k_front", "k_middle", "k_back", "k_carry_fix", "k_sub_small"};
+  return k < kKernels ? names[k] : "";
+}
+
+void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, double* total_ms, double* kernel_ms, size_t kcount) {
+  need_digits(r, "time_square_mul");
+  if (a == 0 || iters == 0) throw std::runtime_error("time_square_mul: factor and iters must be >= 1");
+  HIPCHK(hipSetDevice(device_));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipEventRecord(e0, stream_));
+  for (size_t i = 0; i < iters; ++i) {
+    square_chain(r, a, nullptr);
+    if (sub) HIPCHK(launch_sub_small(dp_, digits(r), sub, stream_));
+  }
+  HIPCHK(hipEventRecord(e1, stream_));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  if (total_ms) *total_ms = ms;
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+
+  if (kernel_ms && kcount) {
+    for (size_t k = 0; k < kcount; ++k) kernel_ms[k] = 0;
+    const size_t reps = std::min<size_t>(iters, 64);
+    const size_t per = 6;
+    std::vector<hipEvent_t> ev(reps * per);
+    for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+    for (size_t i = 0; i < reps; ++i) {
+      square_chain(r, a, &ev[i * per]);
+      if (sub) HIPCHK(launch_sub_small(dp_, digits(r), sub, stream_));
+      HIPCHK(hipEventRecord(ev[i * per + 5], stream_));
+    }
+    HIPCHK(hipStreamSynchronize(stream_));
+    for (size_t i = 0; i < reps; ++i)
+      for (size_t k = 0; k < 5 && k < kcount; ++k) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, ev[i * per + k], ev[i * per + k + 1]));
+        kernel_ms[k] += double(t) / double(reps);
+      }
+    for (auto& x : ev) HIPCHK(hipEventDestroy(x));
+  }
+}
+
+}  // namespace mi355

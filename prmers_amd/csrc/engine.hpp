@@ -1,0 +1,83 @@
+// Engine: one exponent, one HIP device, one stream, reg_count registers.
+// The register machine of the reference's `engine` (include/marin/engine.h:16-303) for the Marin
+// path, re-designed for MI355X (see plan.hpp / kernels.hip).  Exposed through capi.cpp only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+namespace mi355 {
+
+class Engine {
+ public:
+  Engine(uint32_t p, size_t reg_count, int device, bool verbose, const char* spec);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  const Plan& plan() const { return pl_; }
+  size_t n() const { return pl_.n; }
+  size_t word_count() const { return (size_t(pl_.p) + 31) / 32; }
+  size_t reg_count() const { return nregs_; }
+
+  void sync();
+  void set_u32(size_t dst, uint32_t v);
+  void set_digits(size_t dst, const uint64_t* d, size_t count);
+  void get_digits(size_t src, uint64_t* d, size_t count);
+  void set_words(size_t dst, const uint32_t* w, size_t count);
+  void get_words(size_t src, uint32_t* w, size_t count);
+  uint64_t res64(size_t src);
+  void copy(size_t dst, size_t src);
+  void prepare(size_t dst, size_t src);
+  void square_mul(size_t r, uint32_t a);
+  void mul(size_t dst, size_t src, uint32_t a);
+  void add(size_t dst, size_t src);
+  void sub_reg(size_t dst, size_t src);
+  void sub_u32(size_t r, uint32_t v);
+  bool equal(size_t lhs, size_t rhs);
+
+  size_t register_data_size() const { return reg_bytes_ + 8; }
+  void get_data(size_t src, void* data, size_t size);
+  void set_data(size_t dst, const void* data, size_t size);
+  size_t checkpoint_size() const { return nregs_ * register_data_size(); }
+  void get_checkpoint(void* data, size_t size);
+  void set_checkpoint(const void* data, size_t size);
+
+  // measurement
+  static constexpr size_t kKernels = 5;
+  static const char* kernel_name(size_t k);
+  void time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, double* total_ms, double* kernel_ms, size_t kcount);
+  size_t algorithmic_bytes() const { return 48 * pl_.n; }
+
+ private:
+  enum Kind : uint8_t { kDigits = 0, kImage = 1 };
+  void check_reg(size_t r) const;
+  void need_digits(size_t r, const char* op) const;
+  uint32_t* digits(size_t r) { return reinterpret_cast<uint32_t*>(regs_ + r * reg_bytes_); }
+  uint64_t* image(size_t r) { return reinterpret_cast<uint64_t*>(regs_ + r * reg_bytes_); }
+  void read_values(size_t src, std::vector<uint64_t>& v);   // natural order, strongly carried digits
+  void write_values(size_t dst, const std::vector<uint32_t>& natural);
+  void square_chain(size_t r, uint32_t a, hipEvent_t* ev);
+
+  Plan pl_;
+  DevPlan dp_{};
+  int device_ = 0;
+  bool verbose_ = false;
+  hipStream_t stream_ = nullptr;
+  size_t nregs_ = 0, reg_bytes_ = 0;
+  unsigned char* regs_ = nullptr;
+  uint64_t* work_ = nullptr;
+  uint64_t* cbuf_ = nullptr;
+  void* tables_ = nullptr;
+  std::vector<uint8_t> kind_;
+  std::vector<uint8_t> width_;   // natural order
+  std::vector<uint32_t> stage_;  // host staging (one register of digits)
+};
+
+}  // namespace mi355

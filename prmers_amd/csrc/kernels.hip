@@ -1,0 +1,411 @@
+// gfx950 kernels for the Goldilocks IBDWT squaring (generic, size-agnostic set).
+//
+// One squaring x <- x^2 * a mod 2^p-1 is three sweeps over m = n/2 pairs (u64,u64), m = M1 x M2:
+//   k_front : digits(u32, tile-major) -> weight -> length-M1 column DFT (LDS) -> twiddle -> work buffer
+//   k_middle: length-M2 row DFT (LDS) -> pointwise square / multiply mod (t^2 - rho) -> inverse row DFT
+//   k_back  : twiddle^-1 -> inverse column DFT (LDS) -> unweight -> base-2^width carry over runs of 2C
+//             digits -> digits(u32) + one carry word per run
+//   k_carry_fix: adds each run's carry word into the first digits of the next run (weak carry)
+// This replaces the reference's kernel chain forward64_0 / forward256 / sqr512 / backward256 /
+// backward64_0 / carry_weight_mul_p1 / carry_weight_p2 (include/marin/engine_gpu.h:1568-1630,
+// kernels/marin.cl:989-1075,1517-1528,1696-1728,2198-2216).  Butterfly algebra follows
+// marin.cl:304-392 (radix-4 with sqrt(-1), pair squaring mod t^2 - rho), restated for a plain
+// DIF/DIT ordering with universal root tables.
+//
+// All kernels take the geometry in a DevPlan by value; nothing is compiled per exponent.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gf.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+struct alignas(16) P2 { uint64_t a, b; };
+
+__device__ __forceinline__ P2 p2_add(P2 x, P2 y) { return {gf::add(x.a, y.a), gf::add(x.b, y.b)}; }
+__device__ __forceinline__ P2 p2_sub(P2 x, P2 y) { return {gf::sub(x.a, y.a), gf::sub(x.b, y.b)}; }
+__device__ __forceinline__ P2 p2_mul(P2 x, uint64_t w) { return {gf::mul(x.a, w), gf::mul(x.b, w)}; }
+
+// omega_m^e from the two-level table (e < m)
+__device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
+  const uint64_t lo = pl.TWlo[e & ((1u << pl.twh) - 1)], hi = pl.TWhi[e >> pl.twh];
+  return gf::mul(lo, hi);
+}
+
+// column-DFT output slot -> frequency k1 (radix-5 block major, bit reversed inside the block)
+__device__ __forceinline__ uint32_t freq1(const DevPlan& pl, uint32_t pos) {
+  const uint32_t blk = pos / pl.L1, q = pos - blk * pl.L1;
+  const uint32_t rq = pl.logL1 ? (__brev(q) >> (32 - pl.logL1)) : 0u;
+  return blk + pl.r5 * rq;
+}
+
+// p*j mod n for digit (i1, x = 2*i2+b), its width, and whether the factored weight wrapped
+__device__ __forceinline__ void digit_info(const DevPlan& pl, uint32_t sa, uint32_t sb, uint32_t& width, bool& wrap) {
+  uint64_t s = uint64_t(sa) + sb;
+  wrap = (sa > 0) && (sb > 0) && (s <= pl.n);
+  if (s >= pl.n) s -= pl.n;
+  width = pl.q + ((s + pl.t > 0) ? 1u : 0u) + ((s + pl.t > pl.n) ? 1u : 0u) - ((s > 0) ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// radix-4 / radix-2 passes over an LDS array of pairs.
+// Elements of one transform sit at X[(base + i) * stride + col]; `groups` independent transforms of
+// length L (blocks x columns) are processed by the whole work-group.  root[e * rstep] = omega_L^e.
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, uint32_t nblocks, uint32_t ncols,
+                                             const uint64_t* __restrict__ root, uint32_t rootN, uint32_t rstep,
+                                             uint64_t I4, uint32_t tid, uint32_t nthr) {
+  // forward: len = L, L/4, ... (radix-4) then a final radix-2 when log2 L is odd; inverse mirrors
+  const uint32_t n4 = logL / 2, has2 = logL & 1;
+  const uint32_t npass = n4 + has2;
+  for (uint32_t ps = 0; ps < npass; ++ps) {
+    const uint32_t pf = INVERSE ? (npass - 1 - ps) : ps;  // pass index in forward order
+    if (pf < n4) {
+      const uint32_t loglen = logL - 2 * pf, len = 1u << loglen, q = len >> 2;
+      const uint32_t per = L >> 2;  // butterflies per transform
+      const uint32_t total = per * nblocks * ncols;
+      const uint32_t tstep = (L >> loglen) * rstep;  // omega_len^t = root[t * tstep]
+      for (uint32_t idx = tid; idx < total; idx += nthr) {
+        const uint32_t col = idx % ncols, bi = idx / ncols;
+        const uint32_t blk = bi / per, bj = bi - blk * per;
+        const uint32_t sub = bj / q, t = bj - sub * q;
+        const uint32_t e0 = (blk * L + sub * len + t) * ncols + col, es = q * ncols;
+        const uint32_t r1 = t * tstep;
+        P2 x0 = X[e0], x1 = X[e0 + es], x2 = X[e0 + 2 * es], x3 = X[e0 + 3 * es];
+        if (!INVERSE) {
+          const uint64_t w1 = root[r1], w2 = root[2 * r1], w3 = root[3 * r1];
+          const P2 a = p2_add(x0, x2), b = p2_add(x1, x3), c = p2_sub(x0, x2), d = p2_mul(p2_sub(x1, x3), I4);
+          X[e0] = p2_add(a, b);
+          X[e0 + es] = p2_mul(p2_sub(a, b), w2);
+          X[e0 + 2 * es] = p2_mul(p2_add(c, d), w1);
+          X[e0 + 3 * es] = p2_mul(p2_sub(c, d), w3);
+        } else {
+          // inverse roots: omega^-e = root[(N - e) % N]
+          const uint64_t w1 = root[r1 ? rootN - r1 : 0], w2 = root[r1 ? rootN - 2 * r1 : 0], w3 = root[r1 ? rootN - 3 * r1 : 0];
+          const P2 y1 = p2_mul(x1, w2);
+          const P2 A = p2_add(x0, y1), B = p2_sub(x0, y1);
+          const P2 y2 = p2_mul(x2, w1), y3 = p2_mul(x3, w3);
+          const P2 Cc = p2_add(y2, y3), D = p2_mul(p2_sub(y2, y3), I4);  // I4 = omega_4^-1 here
+          X[e0] = p2_add(A, Cc);
+          X[e0 + 2 * es] = p2_sub(A, Cc);
+          X[e0 + es] = p2_add(B, D);
+          X[e0 + 3 * es] = p2_sub(B, D);
+        }
+      }
+    } else {
+      // radix-2, len = 2: no twiddle
+      const uint32_t per = L >> 1, total = per * nblocks * ncols;
+      for (uint32_t idx = tid; idx < total; idx += nthr) {
+        const uint32_t col = idx % ncols, bi = idx / ncols;
+        const uint32_t blk = bi / per, bj = bi - blk * per;
+        const uint32_t e0 = (blk * L + 2 * bj) * ncols + col;
+        const P2 u = X[e0], v = X[e0 + ncols];
+        X[e0] = p2_add(u, v);
+        X[e0 + ncols] = p2_sub(u, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// radix-5 stage of the column DFT (first forward / last inverse): 5 blocks of L1, twiddle omega_M1^(t*k)
+template <bool INVERSE>
+__device__ __forceinline__ void lds_radix5(const DevPlan& pl, P2* X, uint32_t ncols, uint32_t tid, uint32_t nthr) {
+  const uint32_t L1 = pl.L1, total = L1 * ncols;
+  for (uint32_t idx = tid; idx < total; idx += nthr) {
+    const uint32_t col = idx % ncols, t = idx / ncols;
+    P2 x[5], y[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) x[r] = X[(L1 * r + t) * ncols + col];
+    if (!INVERSE) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        P2 s = x[0];
+#pragma unroll
+        for (int r = 1; r < 5; ++r) s = p2_add(s, p2_mul(x[r], pl.W5[(r * k) % 5]));
+        y[k] = (k == 0) ? s : p2_mul(s, pl.UT1[t * k]);  // t*k < M1
+      }
+    } else {
+#pragma unroll
+      for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[(t * k) ? pl.M1 - t * k : 0]);
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        P2 s = x[0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) s = p2_add(s, p2_mul(x[k], pl.W5i[(r * k) % 5]));
+        y[r] = s;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) X[(L1 * r + t) * ncols + col] = y[r];
+  }
+  __syncthreads();
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+// ---------------------------------------------------------------------------------------------
+// front: one work-group per tile T (C adjacent columns, all M1 rows)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_front(DevPlan pl, const uint32_t* __restrict__ digits, uint64_t* __restrict__ Wout) {
+  P2* X = reinterpret_cast<P2*>(smem_raw);
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
+  const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
+  const uint2* dg = reinterpret_cast<const uint2*>(digits) + size_t(T) * tile;
+
+  for (uint32_t e = tid; e < tile; e += nthr) {
+    const uint32_t i1 = e / C, c = e - i1 * C, i2 = T * C + c;
+    const uint2 d = dg[e];
+    const uint32_t sa = pl.SA[i1];
+    const uint64_t ta = pl.TA[i1];
+    uint32_t w0, w1; bool wr0, wr1;
+    digit_info(pl, sa, pl.SB[2 * i2], w0, wr0);
+    digit_info(pl, sa, pl.SB[2 * i2 + 1], w1, wr1);
+    uint64_t a0 = gf::mul_u32(ta, d.x), a1 = gf::mul_u32(ta, d.y);
+    if (wr0) a0 = gf::half(a0);
+    if (wr1) a1 = gf::half(a1);
+    X[e] = {a0, a1};
+  }
+  __syncthreads();
+
+  if (pl.r5 == 5) lds_radix5<false>(pl, X, C, tid, nthr);
+  if (pl.logL1) lds_pow2_dft<false>(X, pl.L1, pl.logL1, pl.r5, C, pl.UT1, M1, pl.r5, pl.I4, tid, nthr);
+
+  P2* W = reinterpret_cast<P2*>(Wout);
+  for (uint32_t e = tid; e < tile; e += nthr) {
+    const uint32_t pos = e / C, c = e - pos * C, i2 = T * C + c;
+    const uint32_t k1 = freq1(pl, pos);
+    const uint64_t ex = (uint64_t(i2) * k1) % pl.m;
+    const uint64_t tw = tw_lookup(pl, ex);
+    const P2 x = X[e];
+    W[size_t(pos) * pl.M2 + i2] = {gf::mul(x.a, gf::mul(tw, pl.TB[2 * i2])), gf::mul(x.b, gf::mul(tw, pl.TB[2 * i2 + 1]))};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// middle: one work-group per row.  mode 0: square, 1: multiply by image Y, 2: forward only.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_middle(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
+                                                uint64_t* __restrict__ Wout, int mode) {
+  P2* X = reinterpret_cast<P2*>(smem_raw);
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x, row = blockIdx.x, M2 = pl.M2;
+  const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * M2;
+  P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * M2;
+
+  for (uint32_t e = tid; e < M2; e += nthr) X[e] = in[e];
+  __syncthreads();
+  lds_pow2_dft<false>(X, M2, pl.logM2, 1, 1, pl.UT2, M2, 1, pl.I4, tid, nthr);
+  if (mode == 2) {
+    for (uint32_t e = tid; e < M2; e += nthr) out[e] = X[e];
+    return;
+  }
+  const uint32_t k1 = freq1(pl, row);
+  const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * M2;
+  for (uint32_t e = tid; e < M2; e += nthr) {
+    const uint32_t k2 = __brev(e) >> (32 - pl.logM2);
+    const uint64_t rho = tw_lookup(pl, uint64_t(k1) + uint64_t(pl.M1) * k2);
+    const P2 u = X[e];
+    P2 r;
+    if (mode == 0) {  // (u0 + u1 t)^2 mod (t^2 - rho), marin.cl:379-384
+      r.a = gf::add(gf::sqr(u.a), gf::mul(gf::sqr(u.b), rho));
+      r.b = gf::mul(u.b, gf::dbl(u.a));
+    } else {          // marin.cl:387-392
+      const P2 y = Y[e];
+      r.a = gf::add(gf::mul(u.a, y.a), gf::mul(gf::mul(u.b, y.b), rho));
+      r.b = gf::add(gf::mul(u.a, y.b), gf::mul(u.b, y.a));
+    }
+    X[e] = r;
+  }
+  __syncthreads();
+  lds_pow2_dft<true>(X, M2, pl.logM2, 1, 1, pl.UT2, M2, 1, pl.I4inv, tid, nthr);
+  for (uint32_t e = tid; e < M2; e += nthr) out[e] = X[e];
+}
+
+// ---------------------------------------------------------------------------------------------
+// back: inverse of front + unweight + carry over the tile's M1 runs of 2C digits
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_back(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+                                              uint64_t* __restrict__ cbuf, uint32_t a) {
+  P2* X = reinterpret_cast<P2*>(smem_raw);
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
+  const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
+  const P2* W = reinterpret_cast<const P2*>(Win);
+
+  for (uint32_t e = tid; e < tile; e += nthr) {
+    const uint32_t pos = e / C, c = e - pos * C, i2 = T * C + c;
+    const uint32_t k1 = freq1(pl, pos);
+    const uint64_t ex = (uint64_t(i2) * k1) % pl.m;
+    const uint64_t tw = tw_lookup(pl, ex ? pl.m - ex : 0);
+    const P2 x = W[size_t(pos) * pl.M2 + i2];
+    X[e] = {gf::mul(x.a, gf::mul(tw, pl.TBi[2 * i2])), gf::mul(x.b, gf::mul(tw, pl.TBi[2 * i2 + 1]))};
+  }
+  __syncthreads();
+
+  if (pl.logL1) lds_pow2_dft<true>(X, pl.L1, pl.logL1, pl.r5, C, pl.UT1, M1, pl.r5, pl.I4inv, tid, nthr);
+  if (pl.r5 == 5) lds_radix5<true>(pl, X, C, tid, nthr);
+
+  uint2* dg = reinterpret_cast<uint2*>(digits) + size_t(T) * tile;
+  for (uint32_t i1 = tid; i1 < M1; i1 += nthr) {
+    const uint32_t sa = pl.SA[i1];
+    const uint64_t tai = pl.TAi[i1];
+    uint64_t carry = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+      const uint32_t i2 = T * C + c;
+      const P2 x = X[i1 * C + c];
+      uint32_t out[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        uint32_t width; bool wrap;
+        digit_info(pl, sa, pl.SB[2 * i2 + b], width, wrap);
+        uint64_t u = gf::mul(b ? x.b : x.a, tai);
+        if (wrap) u = gf::dbl(u);
+        // adc_mul (marin.cl:194-201): digit first, so that everything stays in 64 bits
+        const uint64_t mask = (uint64_t(1) << width) - 1;
+        const uint64_t dlo = u & mask, chi = u >> width;
+        const uint64_t r = dlo * a + carry;
+        out[b] = uint32_t(r & mask);
+        carry = (r >> width) + chi * a;
+      }
+      dg[i1 * C + c] = make_uint2(out[0], out[1]);
+    }
+    cbuf[size_t(T) * M1 + i1] = carry;
+  }
+}
+
+// previous run (in digit order) of run (T, i1): same row, previous tile; first tile wraps to the
+// last tile of the previous row (cyclic: 2^p = 1)
+__device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_t* cbuf, uint32_t T, uint32_t i1) {
+  const uint32_t NT = pl.M2 / pl.C;
+  if (T > 0) return cbuf[size_t(T - 1) * pl.M1 + i1];
+  return cbuf[size_t(NT - 1) * pl.M1 + (i1 ? i1 - 1 : pl.M1 - 1)];
+}
+
+// carry fix: one thread per run; weak carry (the remainder, if any, stays on the run's last digit:
+// same contract as adc4, marin.cl:203-212)
+__global__ void __launch_bounds__(256) k_carry_fix(DevPlan pl, uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf) {
+  const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M1 = pl.M1, C = pl.C, NT = pl.M2 / C;
+  if (run >= M1 * NT) return;
+  const uint32_t T = run / M1, i1 = run - T * M1;
+  uint64_t cin = carry_in_of(pl, cbuf, T, i1);
+  if (cin == 0) return;
+  uint32_t* d = digits + (size_t(T) * M1 + i1) * C * 2;
+  const uint32_t sa = pl.SA[i1];
+  for (uint32_t k = 0; k < 2 * C; ++k) {
+    if (k == 2 * C - 1) { d[k] += uint32_t(cin); break; }
+    uint32_t width; bool wrap;
+    digit_info(pl, sa, pl.SB[2 * (T * C) + k], width, wrap);
+    const uint64_t v = uint64_t(d[k]) + cin;
+    d[k] = uint32_t(v & ((uint64_t(1) << width) - 1));
+    cin = v >> width;
+    if (cin == 0) break;
+  }
+}
+
+// dst <- dst + src   (negate = 0)   or   dst <- dst - src + 2*Mp  (negate = 1; neg2_mp4, marin.cl:246-256)
+__global__ void __launch_bounds__(256) k_addsub(DevPlan pl, uint32_t* __restrict__ dst, const uint32_t* __restrict__ src,
+                                                uint64_t* __restrict__ cbuf, int negate) {
+  const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M1 = pl.M1, C = pl.C, NT = pl.M2 / C;
+  if (run >= M1 * NT) return;
+  const uint32_t T = run / M1, i1 = run - T * M1;
+  uint32_t* d = dst + (size_t(T) * M1 + i1) * C * 2;
+  const uint32_t* s = src + (size_t(T) * M1 + i1) * C * 2;
+  const uint32_t sa = pl.SA[i1];
+  uint64_t carry = 0;
+  for (uint32_t k = 0; k < 2 * C; ++k) {
+    uint32_t width; bool wrap;
+    digit_info(pl, sa, pl.SB[2 * (T * C) + k], width, wrap);
+    const uint64_t mask = (uint64_t(1) << width) - 1;
+    uint64_t sv = s[k];
+    if (negate) sv = 2 * mask - sv;   // src digits are < 2^width + small: keep it non-negative
+    const uint64_t v = uint64_t(d[k]) + sv + carry;
+    d[k] = uint32_t(v & mask);
+    carry = v >> width;
+  }
+  cbuf[size_t(T) * M1 + i1] = carry;
+}
+
+// digit j -> memory slot (Plan::pos)
+__device__ __forceinline__ size_t slot_of(const DevPlan& pl, uint32_t j) {
+  const uint32_t i = j >> 1, b = j & 1;
+  const uint32_t i1 = i / pl.M2, i2 = i - i1 * pl.M2;
+  const uint32_t T = i2 / pl.C, c = i2 - T * pl.C;
+  return ((size_t(T) * pl.M1 + i1) * pl.C + c) * 2 + b;
+}
+
+// x <- x - a with borrow, one thread (marin.cl:2376-2393)
+__global__ void k_sub_small(DevPlan pl, uint32_t* __restrict__ digits, uint32_t a) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint64_t borrow = a;
+  for (int lap = 0; lap < 3 && borrow; ++lap) {
+    for (uint32_t j = 0; j < pl.n && borrow; ++j) {
+      const uint32_t i = j >> 1, i1 = i / pl.M2, i2 = i - i1 * pl.M2;
+      uint32_t width; bool wrap;
+      digit_info(pl, pl.SA[i1], pl.SB[2 * i2 + (j & 1)], width, wrap);
+      const size_t s = slot_of(pl, j);
+      const uint64_t dv = digits[s];
+      if (dv >= borrow) { digits[s] = uint32_t(dv - borrow); borrow = 0; }
+      else {
+        // borrow k units of 2^width: smallest k with dv + k*2^width >= borrow
+        const uint64_t need = borrow - dv;
+        const uint64_t k = (need + (uint64_t(1) << width) - 1) >> width;
+        digits[s] = uint32_t(dv + (k << width) - borrow);
+        borrow = k;
+      }
+    }
+  }
+}
+
+// ------------------------------- launch wrappers ---------------------------------------------
+
+static inline uint32_t block_for(size_t work) {
+  size_t b = 64;
+  while (b < 256 && b < work) b <<= 1;
+  return uint32_t(b);
+}
+
+hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, uint64_t* W, hipStream_t s) {
+  const size_t tile = size_t(pl.M1) * pl.C;
+  hipLaunchKernelGGL(k_front, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, digits, W);
+  return hipGetLastError();
+}
+hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(k_middle, dim3(pl.M1), dim3(block_for(pl.M2 / 4 ? pl.M2 / 4 : 1)), size_t(pl.M2) * 16, s, pl, Win, Y, Wout, mode);
+  return hipGetLastError();
+}
+hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s) {
+  const size_t tile = size_t(pl.M1) * pl.C;
+  hipLaunchKernelGGL(k_back, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, W, digits, cbuf, a);
+  return hipGetLastError();
+}
+hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t* cbuf, hipStream_t s) {
+  const size_t runs = size_t(pl.M1) * (pl.M2 / pl.C);
+  hipLaunchKernelGGL(k_carry_fix, dim3((runs + 255) / 256), dim3(256), 0, s, pl, digits, cbuf);
+  return hipGetLastError();
+}
+hipError_t launch_addsub(const DevPlan& pl, uint32_t* dst, const uint32_t* src, uint64_t* cbuf, int negate, hipStream_t s) {
+  const size_t runs = size_t(pl.M1) * (pl.M2 / pl.C);
+  hipLaunchKernelGGL(k_addsub, dim3((runs + 255) / 256), dim3(256), 0, s, pl, dst, src, cbuf, negate);
+  return hipGetLastError();
+}
+hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hipStream_t s) {
+  hipLaunchKernelGGL(k_sub_small, dim3(1), dim3(64), 0, s, pl, digits, a);
+  return hipGetLastError();
+}
+hipError_t configure_kernels(size_t lds_front, size_t lds_mid) {
+  hipError_t e = hipSuccess;
+  if (lds_front > 48 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_front));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_back), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_front));
+    if (e != hipSuccess) return e;
+  }
+  if (lds_mid > 48 * 1024)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_middle), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_mid));
+  return e;
+}
+
+}  // namespace mi355

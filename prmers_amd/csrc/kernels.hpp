@@ -1,0 +1,25 @@
+// Device-side view of a Plan and the kernel launch entry points (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355 {
+
+struct DevPlan {
+  uint32_t n, m, M1, M2, L1, logL1, logM2, r5, C, q, t, twh;
+  const uint32_t *SA, *SB;
+  const uint64_t *TA, *TAi, *TB, *TBi;
+  const uint64_t *TWlo, *TWhi, *UT1, *UT2;
+  uint64_t I4, I4inv;
+  uint64_t W5[5], W5i[5];
+};
+
+hipError_t configure_kernels(size_t lds_front, size_t lds_mid);
+hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, uint64_t* W, hipStream_t s);
+hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s);
+hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
+hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t* cbuf, hipStream_t s);
+hipError_t launch_addsub(const DevPlan& pl, uint32_t* dst, const uint32_t* src, uint64_t* cbuf, int negate, hipStream_t s);
+hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hipStream_t s);
+
+}  // namespace mi355

@@ -1,0 +1,194 @@
+// Transform plan for one exponent: sizes, tile geometry and the small host-built tables.
+//
+// Host-only (no HIP), so the size policy and the index maps are testable without a GPU.
+//
+// Reference behaviour kept:  n = ibdwt::transform_size(p) (include/marin/ibdwt.h:17-43), digit
+// widths ceil(p(j+1)/n) - ceil(pj/n) (ibdwt.h:127-132), weights 2^frac(-pj/n) built from
+// nr2 = 554^((P-1)/192/n) (ibdwt.h:116-143), roots from generator 7 (arith.h:72).
+// What is different by design (MI355X-first):
+//   * the length-m (m = n/2 pairs) transform is a two-level decomposition m = M1 x M2 ("columns" of
+//     length M1 at stride M2, then contiguous rows of length M2) so one squaring is three sweeps
+//     (front, middle, back) instead of the reference's five transform kernels + two carry kernels;
+//   * the weights are never stored per digit: w_j = TA[i1] * TB[2*i2+b] / (wrap ? 2 : 1) with
+//     M1 + 2*M2 table entries (the reference streams a 2n-word table, 128 MiB at n = 2^23);
+//   * registers hold UNWEIGHTED digits as u32 in a tile-major order chosen so that both the front
+//     and the back sweep touch them fully coalesced.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gf.hpp"
+
+namespace mi355 {
+
+inline size_t transform_size(uint32_t exponent) {
+  // ibdwt.h:17-43: smallest n in {2^k, 5*2^k}, k <= 26, with 2*(floor(p/n)+1) + log2(n) < 64
+  uint32_t w = 0, log2_n = 1, log2_n5 = 2;
+  do { ++log2_n; w = exponent >> log2_n; } while ((w + 1) * 2 + log2_n >= 64);
+  do { ++log2_n5; w = exponent / (5u << log2_n5); } while ((w + 1) * 2 + (log2_n5 + 2.4) >= 64);
+  const size_t invalid = size_t(-1);
+  const size_t n2 = (log2_n <= 26) ? (size_t(1) << log2_n) : invalid;
+  const size_t n5 = (log2_n5 <= 26) ? (size_t(5) << log2_n5) : invalid;
+  return n2 < n5 ? n2 : n5;
+}
+
+inline int ilog2(size_t v) { int r = -1; while (v) { v >>= 1; ++r; } return r; }
+
+inline uint32_t bitrev(uint32_t i, int bits) {
+  uint32_t r = 0;
+  for (int k = 0; k < bits; ++k) { r = (r << 1) | (i & 1); i >>= 1; }
+  return r;
+}
+
+struct Plan {
+  uint32_t p = 0;
+  size_t n = 0, m = 0;      // digits, pairs
+  uint32_t r5 = 1;          // 1 or 5
+  uint32_t M1 = 1, M2 = 1;  // m = M1 * M2, M2 = 2^logM2, M1 = r5 * L1, L1 = 2^logL1
+  uint32_t L1 = 1, logL1 = 0, logM2 = 0;
+  uint32_t C = 1;           // adjacent columns per front/back tile (runs of 2C digits)
+  uint32_t q = 0, t = 0;    // p = q*n + t
+  uint32_t twh = 0;         // omega_m^e = TWlo[e & (2^twh-1)] * TWhi[e >> twh]
+  size_t lds_front = 0, lds_mid = 0;
+
+  // host tables (uploaded as-is)
+  std::vector<uint32_t> SA, SB;          // p*j mod n split: SA[i1] + SB[2*i2+b]
+  std::vector<uint64_t> TA, TAi, TB, TBi;  // 2^(1/n) powers; TAi carries the 1/m factor
+  std::vector<uint64_t> TWlo, TWhi;      // two-level omega_m table
+  std::vector<uint64_t> UT1, UT2;        // omega_M1^e (e < M1), omega_M2^e (e < M2)
+  uint64_t I4 = 0, I4inv = 0;            // omega_4, omega_4^-1 (forward root convention)
+  uint64_t W5[5] = {1, 0, 0, 0, 0}, W5i[5] = {1, 0, 0, 0, 0};
+
+  size_t tiles() const { return M2 / C; }
+  size_t runs() const { return tiles() * M1; }
+
+  // width of digit with s = p*j mod n   (derivation: DESIGN.md "digit widths on the fly")
+  uint32_t width_of_s(uint64_t s) const {
+    return q + ((s + t > 0) ? 1u : 0u) + ((s + t > n) ? 1u : 0u) - ((s > 0) ? 1u : 0u);
+  }
+  uint32_t width(size_t j) const { return width_of_s((uint64_t(p) * j) % n); }
+
+  // memory position (u32 index) of natural digit j inside a register (tile-major)
+  size_t pos(size_t j) const {
+    const size_t i = j >> 1, b = j & 1;
+    const size_t i1 = i / M2, i2 = i % M2;
+    const size_t T = i2 / C, c = i2 % C;
+    return ((T * M1 + i1) * C + c) * 2 + b;
+  }
+
+  std::string describe() const {
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "marin-hip:n=%zu:m1=%u:m2=%u:c=%u", n, M1, M2, C);
+    return buf;
+  }
+};
+
+// spec: "" (auto) or comma/colon separated "m2=<pow2>", "c=<pow2>"
+inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables = true) {
+  if (p < 3) throw std::runtime_error("exponent must be >= 3");
+  Plan pl;
+  pl.p = p;
+  pl.n = transform_size(p);
+  if (pl.n == size_t(-1)) throw std::runtime_error("exponent too large for the Goldilocks IBDWT");
+  pl.m = pl.n / 2;
+  pl.r5 = (pl.m % 5 == 0) ? 5 : 1;
+  const int k = ilog2(pl.m / pl.r5);
+
+  long want_m2 = -1, want_c = -1;
+  if (spec && *spec) {
+    std::string s(spec);
+    for (size_t i = 0; i < s.size();) {
+      size_t e = s.find_first_of(",:; ", i);
+      if (e == std::string::npos) e = s.size();
+      const std::string tok = s.substr(i, e - i);
+      if (tok.rfind("m2=", 0) == 0) want_m2 = std::atol(tok.c_str() + 3);
+      else if (tok.rfind("c=", 0) == 0) want_c = std::atol(tok.c_str() + 2);
+      else if (!tok.empty() && tok != "marin-hip" && tok.rfind("n=", 0) != 0 && tok.rfind("m1=", 0) != 0)
+        throw std::runtime_error("unknown plan token '" + tok + "'");
+      i = e + 1;
+    }
+  }
+
+  // rows vs columns: balance the work-group counts of the row sweep (M1 groups) and the column
+  // sweeps (M2/C groups), keep a row <= 4096 pairs (64 KiB of LDS) and a column <= 1024 (x r5)
+  int b = (k + 3) / 2;
+  const int bmin = k - (pl.r5 == 5 ? 8 : 10);
+  if (b < bmin) b = bmin;
+  if (b > 12) b = 12;
+  if (b > k) b = k;
+  if (b < 1) b = 1;
+  if (want_m2 > 0) {
+    b = ilog2(size_t(want_m2));
+    if ((long(1) << b) != want_m2 || b > k || b < 1 || b > 13) throw std::runtime_error("bad m2 in plan spec");
+  } else {
+    // very large transforms: 8192-pair rows (128 KiB) so that M1 stays <= 2048
+    while ((pl.m >> b) > 2048 && b < 13 && b < k) ++b;
+  }
+  pl.logM2 = uint32_t(b);
+  pl.M2 = 1u << b;
+  pl.M1 = uint32_t(pl.m / pl.M2);
+  pl.L1 = pl.M1 / pl.r5;
+  pl.logL1 = uint32_t(ilog2(pl.L1));
+  if (pl.M1 > 2560) throw std::runtime_error("transform size not supported yet (n > 5*2^23)");
+
+  // tile: up to 4096 pairs (64 KiB), runs of at most 16 pairs (256 B of the work buffer);
+  // grow to 8192 pairs (128 KiB) when that is what C >= 4 needs
+  uint32_t C = 1;
+  while (C * 2 <= pl.M2 && size_t(pl.M1) * (C * 2) <= 4096 && C < 16) C *= 2;
+  while (C < 4 && C * 2 <= pl.M2 && size_t(pl.M1) * (C * 2) <= 8192) C *= 2;
+  while (C > 4 && pl.M2 / C < 256) C /= 2;   // mid-size transforms: enough tiles to fill 256 CUs
+  if (want_c > 0) {
+    C = uint32_t(want_c);
+    if ((C & (C - 1)) != 0 || C > pl.M2 || size_t(pl.M1) * C > 8192) throw std::runtime_error("bad c in plan spec");
+  }
+  pl.C = C;
+  pl.lds_front = size_t(pl.M1) * pl.C * 16;
+  pl.lds_mid = size_t(pl.M2) * 16;
+  pl.q = uint32_t(p / pl.n);
+  pl.t = uint32_t(p % pl.n);
+  if (!build_tables) return pl;
+
+  const size_t n = pl.n, m = pl.m;
+  const uint64_t r = gf::root_of_two(n);   // 2^(1/n)
+  const uint64_t om = gf::root_of_unity(m);
+  const uint64_t inv_m = gf::inv(uint64_t(m) % gf::P);
+
+  pl.SA.resize(pl.M1); pl.TA.resize(pl.M1); pl.TAi.resize(pl.M1);
+  for (uint32_t i1 = 0; i1 < pl.M1; ++i1) {
+    const uint64_t s = (uint64_t(2) * pl.M2 % n * (uint64_t(p) % n) % n * i1) % n;
+    pl.SA[i1] = uint32_t(s);
+    pl.TA[i1] = gf::pow(r, (n - s) % n);
+    pl.TAi[i1] = gf::mul(gf::inv(pl.TA[i1]), inv_m);
+  }
+  pl.SB.resize(2 * size_t(pl.M2)); pl.TB.resize(2 * size_t(pl.M2)); pl.TBi.resize(2 * size_t(pl.M2));
+  for (uint32_t x = 0; x < 2 * pl.M2; ++x) {
+    const uint64_t s = (uint64_t(p) * x) % n;
+    pl.SB[x] = uint32_t(s);
+    pl.TB[x] = gf::pow(r, (n - s) % n);
+    pl.TBi[x] = gf::inv(pl.TB[x]);
+  }
+  pl.twh = uint32_t((ilog2(m) + 2) / 2);
+  const size_t lo_n = size_t(1) << pl.twh, hi_n = (m >> pl.twh) + 1;
+  pl.TWlo.resize(lo_n); pl.TWhi.resize(hi_n);
+  pl.TWlo[0] = 1; for (size_t i = 1; i < lo_n; ++i) pl.TWlo[i] = gf::mul(pl.TWlo[i - 1], om);
+  const uint64_t step = gf::mul(pl.TWlo[lo_n - 1], om);
+  pl.TWhi[0] = 1; for (size_t i = 1; i < hi_n; ++i) pl.TWhi[i] = gf::mul(pl.TWhi[i - 1], step);
+  const uint64_t om1 = gf::pow(om, pl.M2), om2 = gf::pow(om, pl.M1);
+  pl.UT1.resize(pl.M1); pl.UT1[0] = 1; for (uint32_t i = 1; i < pl.M1; ++i) pl.UT1[i] = gf::mul(pl.UT1[i - 1], om1);
+  pl.UT2.resize(pl.M2); pl.UT2[0] = 1; for (uint32_t i = 1; i < pl.M2; ++i) pl.UT2[i] = gf::mul(pl.UT2[i - 1], om2);
+  if (m % 4 == 0) { pl.I4 = gf::pow(om, m / 4); pl.I4inv = gf::inv(pl.I4); }
+  else { pl.I4 = gf::root_of_unity(4); pl.I4inv = gf::inv(pl.I4); }
+  if (pl.r5 == 5) {
+    const uint64_t w5 = gf::pow(om, m / 5);
+    for (int i = 0; i < 5; ++i) { pl.W5[i] = gf::pow(w5, uint64_t(i)); pl.W5i[i] = gf::inv(pl.W5[i]); }
+  }
+  return pl;
+}
+
+}  // namespace mi355

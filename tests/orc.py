@@ -33,7 +33,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
+        # never oversubscribe: a GPU box exposes the host's cores but only a share of them is ours
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(LIB_PATH)
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads(int(os.environ.get("ORACLE_THREADS", max(1, min(ncpu, 16)))))
         u64, u32, sz, vp = C.c_uint64, C.c_uint32, C.c_size_t, C.c_void_p
         sig = {
             "orc_mod_add": (u64, [u64, u64]), "orc_mod_sub": (u64, [u64, u64]), "orc_mod_mul": (u64, [u64, u64]),
