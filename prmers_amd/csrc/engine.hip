@@ -2,6 +2,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace mi355 {
@@ -37,9 +38,11 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&regs_), nregs_ * reg_bytes_));
   HIPCHK(hipMemsetAsync(regs_, 0, nregs_ * reg_bytes_, stream_));
   HIPCHK(hipMalloc(reinterpret_cast<void**>(&work_), reg_bytes_));
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&cbuf_), pl_.runs() * 8));
-  HIPCHK(hipMemsetAsync(cbuf_, 0, pl_.runs() * 8, stream_));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&cbuf_), nregs_ * pl_.runs() * 8));
+  HIPCHK(hipMemsetAsync(cbuf_, 0, nregs_ * pl_.runs() * 8, stream_));
   kind_.assign(nregs_, kDigits);
+  pending_carry_.assign(nregs_, 0);
+  pending_sub_.assign(nregs_, 0);
 
   // one allocation for all tables
   auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
@@ -68,6 +71,15 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   dp_.I4 = pl_.I4; dp_.I4inv = pl_.I4inv;
   for (int i = 0; i < 5; ++i) { dp_.W5[i] = pl_.W5[i]; dp_.W5i[i] = pl_.W5i[i]; }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
+  {
+    // kernel set: the register-resident radix-8 kernels where the shape is served, else the generic
+    // set.  MI355_KERNELS=generic|v2rows|v2cols narrows it (A/B tests, debugging).
+    const char* ks = std::getenv("MI355_KERNELS");
+    const std::string sel = ks ? ks : "v2";
+    v2rows_ = (sel == "v2" || sel == "v2rows") && v2_rows_supported(dp_);
+    v2cols_ = (sel == "v2" || sel == "v2cols") && v2_cols_supported(dp_);
+    if (v2rows_ || v2cols_) HIPCHK(v2_configure());
+  }
 
   // digit widths in natural order (ibdwt.h:127-132), s_j = p*j mod n kept incrementally
   width_.resize(pl_.n);
@@ -103,6 +115,46 @@ void Engine::sync() {
   HIPCHK(hipStreamSynchronize(stream_));
 }
 
+void Engine::normalize(size_t r) {
+  if (kind_[r] != kDigits) return;
+  if (pending_carry_[r]) {
+    HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_));
+    pending_carry_[r] = 0;
+  }
+  if (pending_sub_[r]) {
+    HIPCHK(launch_sub_small(dp_, digits(r), pending_sub_[r], stream_));
+    pending_sub_[r] = 0;
+  }
+}
+
+void Engine::run_front(size_t r) {
+  if (v2cols_) {
+    HIPCHK(v2_launch_front(dp_, digits(r), pending_carry_[r] ? cbuf(r) : nullptr, pending_sub_[r], work_, stream_));
+  } else {
+    normalize(r);
+    HIPCHK(launch_front(dp_, digits(r), work_, stream_));
+  }
+}
+
+void Engine::run_middle(const uint64_t* in, const uint64_t* y, uint64_t* out, int mode) {
+  if (v2rows_) HIPCHK(v2_launch_middle(dp_, in, y, out, mode, stream_));
+  else HIPCHK(launch_middle(dp_, in, y, out, mode, stream_));
+}
+
+// work_ -> digits(r) (+ run carries in cbuf(r)); the carry fix is deferred to the next front sweep
+// when that kernel can fold it in, otherwise applied right away
+void Engine::run_back(size_t r, uint32_t a) {
+  if (v2cols_) {
+    HIPCHK(v2_launch_back(dp_, work_, digits(r), cbuf(r), a, stream_));
+    pending_carry_[r] = 1;
+  } else {
+    HIPCHK(launch_back(dp_, work_, digits(r), cbuf(r), a, stream_));
+    HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_));
+    pending_carry_[r] = 0;
+  }
+  pending_sub_[r] = 0;
+}
+
 // ---- host digit I/O -------------------------------------------------------------------------
 
 void Engine::write_values(size_t dst, const std::vector<uint32_t>& natural) {
@@ -118,12 +170,14 @@ void Engine::write_values(size_t dst, const std::vector<uint32_t>& natural) {
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(digits(dst), stage_.data(), pl_.n * 4, hipMemcpyHostToDevice));
   kind_[dst] = kDigits;
+  pending_carry_[dst] = 0; pending_sub_[dst] = 0;
 }
 
 void Engine::read_values(size_t src, std::vector<uint64_t>& v) {
   need_digits(src, "get");
   stage_.resize(pl_.n);
   HIPCHK(hipSetDevice(device_));
+  normalize(src);
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(stage_.data(), digits(src), pl_.n * 4, hipMemcpyDeviceToHost));
   v.resize(pl_.n);
@@ -165,6 +219,7 @@ void Engine::set_u32(size_t dst, uint32_t value) {
     if (d) HIPCHK(hipMemcpy(digits(dst) + pl_.pos(j), &d, 4, hipMemcpyHostToDevice));
   }
   kind_[dst] = kDigits;
+  pending_carry_[dst] = 0; pending_sub_[dst] = 0;
 }
 
 void Engine::set_digits(size_t dst, const uint64_t* d, size_t count) {
@@ -255,6 +310,8 @@ void Engine::copy(size_t dst, size_t src) {
   check_reg(dst); check_reg(src);
   if (dst == src) return;
   HIPCHK(hipSetDevice(device_));
+  normalize(src);
+  pending_carry_[dst] = 0; pending_sub_[dst] = 0;
   const size_t bytes = (kind_[src] == kDigits) ? pl_.n * 4 : reg_bytes_;
   HIPCHK(hipMemcpyAsync(regs_ + dst * reg_bytes_, regs_ + src * reg_bytes_, bytes, hipMemcpyDeviceToDevice, stream_));
   kind_[dst] = kind_[src];
@@ -262,14 +319,22 @@ void Engine::copy(size_t dst, size_t src) {
 
 void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
   if (ev) HIPCHK(hipEventRecord(ev[0], stream_));
-  HIPCHK(launch_front(dp_, digits(r), work_, stream_));
+  run_front(r);
   if (ev) HIPCHK(hipEventRecord(ev[1], stream_));
-  HIPCHK(launch_middle(dp_, work_, nullptr, work_, 0, stream_));
+  run_middle(work_, nullptr, work_, 0);
   if (ev) HIPCHK(hipEventRecord(ev[2], stream_));
-  HIPCHK(launch_back(dp_, work_, digits(r), cbuf_, a, stream_));
-  if (ev) HIPCHK(hipEventRecord(ev[3], stream_));
-  HIPCHK(launch_carry_fix(dp_, digits(r), cbuf_, stream_));
-  if (ev) HIPCHK(hipEventRecord(ev[4], stream_));
+  if (v2cols_) {
+    HIPCHK(v2_launch_back(dp_, work_, digits(r), cbuf(r), a, stream_));
+    if (ev) { HIPCHK(hipEventRecord(ev[3], stream_)); HIPCHK(hipEventRecord(ev[4], stream_)); }
+    pending_carry_[r] = 1;
+  } else {
+    HIPCHK(launch_back(dp_, work_, digits(r), cbuf(r), a, stream_));
+    if (ev) HIPCHK(hipEventRecord(ev[3], stream_));
+    HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_));
+    if (ev) HIPCHK(hipEventRecord(ev[4], stream_));
+    pending_carry_[r] = 0;
+  }
+  pending_sub_[r] = 0;
 }
 
 void Engine::square_mul(size_t r, uint32_t a) {
@@ -283,9 +348,11 @@ void Engine::prepare(size_t dst, size_t src) {
   need_digits(src, "set_multiplicand");
   check_reg(dst);
   HIPCHK(hipSetDevice(device_));
-  HIPCHK(launch_front(dp_, digits(src), work_, stream_));
-  HIPCHK(launch_middle(dp_, work_, nullptr, image(dst), 2, stream_));
+  run_front(src);
+  run_middle(work_, nullptr, image(dst), 2);
+  if (dst != src && v2cols_) { /* src keeps its pending state: the front sweep only read it */ }
   kind_[dst] = kImage;
+  pending_carry_[dst] = 0; pending_sub_[dst] = 0;
 }
 
 void Engine::mul(size_t dst, size_t src, uint32_t a) {
@@ -295,30 +362,33 @@ void Engine::mul(size_t dst, size_t src, uint32_t a) {
   if (dst == src) throw std::runtime_error("mul: dst and src must differ");
   if (a == 0) throw std::runtime_error("mul: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  HIPCHK(launch_front(dp_, digits(dst), work_, stream_));
-  HIPCHK(launch_middle(dp_, work_, image(src), work_, 1, stream_));
-  HIPCHK(launch_back(dp_, work_, digits(dst), cbuf_, a, stream_));
-  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf_, stream_));
+  run_front(dst);
+  run_middle(work_, image(src), work_, 1);
+  run_back(dst, a);
 }
 
 void Engine::add(size_t dst, size_t src) {
   need_digits(dst, "add"); need_digits(src, "add");
   HIPCHK(hipSetDevice(device_));
-  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf_, 0, stream_));
-  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf_, stream_));
+  normalize(dst); normalize(src);
+  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf(dst), 0, stream_));
+  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf(dst), stream_));
 }
 
 void Engine::sub_reg(size_t dst, size_t src) {
   need_digits(dst, "sub_reg"); need_digits(src, "sub_reg");
   HIPCHK(hipSetDevice(device_));
-  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf_, 1, stream_));
-  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf_, stream_));
+  normalize(dst); normalize(src);
+  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf(dst), 1, stream_));
+  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf(dst), stream_));
 }
 
 void Engine::sub_u32(size_t r, uint32_t v) {
   need_digits(r, "sub");
   if (v == 0) return;
   HIPCHK(hipSetDevice(device_));
+  if (v2cols_ && uint64_t(pending_sub_[r]) + v < (1u << 30)) { pending_sub_[r] += v; return; }  // folded into the next front sweep
+  normalize(r);
   HIPCHK(launch_sub_small(dp_, digits(r), v, stream_));
 }
 
@@ -328,6 +398,7 @@ void Engine::get_data(size_t src, void* data, size_t size) {
   check_reg(src);
   if (size != register_data_size()) throw std::runtime_error("get_data: size mismatch");
   HIPCHK(hipSetDevice(device_));
+  normalize(src);
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(data, regs_ + src * reg_bytes_, reg_bytes_, hipMemcpyDeviceToHost));
   const uint64_t tag = kind_[src];
@@ -344,6 +415,7 @@ void Engine::set_data(size_t dst, const void* data, size_t size) {
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(regs_ + dst * reg_bytes_, data, reg_bytes_, hipMemcpyHostToDevice));
   kind_[dst] = uint8_t(tag);
+  pending_carry_[dst] = 0; pending_sub_[dst] = 0;
 }
 
 void Engine::get_checkpoint(void* data, size_t size) {
@@ -373,7 +445,7 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
   HIPCHK(hipEventRecord(e0, stream_));
   for (size_t i = 0; i < iters; ++i) {
     square_chain(r, a, nullptr);
-    if (sub) HIPCHK(launch_sub_small(dp_, digits(r), sub, stream_));
+    if (sub) sub_u32(r, sub);
   }
   HIPCHK(hipEventRecord(e1, stream_));
   HIPCHK(hipEventSynchronize(e1));
@@ -390,7 +462,7 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
     for (auto& x : ev) HIPCHK(hipEventCreate(&x));
     for (size_t i = 0; i < reps; ++i) {
       square_chain(r, a, &ev[i * per]);
-      if (sub) HIPCHK(launch_sub_small(dp_, digits(r), sub, stream_));
+      if (sub) sub_u32(r, sub);
       HIPCHK(hipEventRecord(ev[i * per + 5], stream_));
     }
     HIPCHK(hipStreamSynchronize(stream_));

@@ -64,6 +64,11 @@ class Engine {
   void read_values(size_t src, std::vector<uint64_t>& v);   // natural order, strongly carried digits
   void write_values(size_t dst, const std::vector<uint32_t>& natural);
   void square_chain(size_t r, uint32_t a, hipEvent_t* ev);
+  uint64_t* cbuf(size_t r) { return cbuf_ + r * pl_.runs(); }
+  void normalize(size_t r);          // apply deferred run carries / small subtraction
+  void run_front(size_t r);          // digits(r) -> work_, consuming pending state when the kernel can
+  void run_middle(const uint64_t* in, const uint64_t* y, uint64_t* out, int mode);
+  void run_back(size_t r, uint32_t a);
 
   Plan pl_;
   DevPlan dp_{};
@@ -76,6 +81,9 @@ class Engine {
   uint64_t* cbuf_ = nullptr;
   void* tables_ = nullptr;
   std::vector<uint8_t> kind_;
+  std::vector<uint8_t> pending_carry_;   // cbuf(r) not yet folded into the digits
+  std::vector<uint32_t> pending_sub_;    // small constant still to subtract (LL's -2)
+  bool v2rows_ = false, v2cols_ = false;
   std::vector<uint8_t> width_;   // natural order
   std::vector<uint32_t> stage_;  // host staging (one register of digits)
 };

@@ -85,11 +85,14 @@ GF_HD uint64_t mul_u32(uint64_t a, uint32_t b) {
   uint64_t hi = t1 >> 32;  // < 2^32: hh = 0
   // lo + hi*(2^32-1)
   uint64_t s = (hi << 32) - hi;  // < P
-  return add(lo >= P ? lo - P : lo, s);
+  return add(lo, s);  // lo may be >= P: see mul_pow2's note
 }
 
-// a * 2^s for 0 <= s < 192 (2 is a primitive 192nd root of unity, 2^96 = -1).
-// With s a compile-time constant after inlining this is shifts and a few add/sub.
+// a * 2^s for 0 <= s < 192 (2 is a primitive 192nd root of unity, 2^96 = -1); a canonical.
+// With s a compile-time constant after inlining, or wave-uniform (scalar branches), this is a few
+// shifts and one or two modular add/sub -- a third to a half of a general mul().
+// add() below is called with a possibly non-canonical first operand (< 2^64) and a second operand
+// <= (2^32-1)^2; it still returns the canonical sum ("lazy operands of add").
 GF_HD uint64_t mul_pow2(uint64_t a, unsigned s) {
   bool negate = false;
   if (s >= 96) { s -= 96; negate = true; }
@@ -97,38 +100,24 @@ GF_HD uint64_t mul_pow2(uint64_t a, unsigned s) {
   if (s == 0) {
     r = a;
   } else if (s < 32) {
-    // a*2^s = hi*2^64 + lo, hi < 2^32
-    uint64_t lo = a << s, hi = a >> (64 - s);
-    uint64_t t = (hi << 32) - hi;  // hi*(2^32-1) < P
-    r = add(lo >= P ? lo - P : lo, t);
-  } else if (s == 32) {
-    // a = ah*2^32 + al:  a*2^32 = ah*2^64 + al*2^32 = ah*(2^32-1) + al*2^32
-    uint64_t ah = a >> 32, al = a & 0xffffffffull;
-    uint64_t t = (ah << 32) - ah;
-    uint64_t u = al << 32;
-    r = add(u >= P ? u - P : u, t);
+    // a*2^s = hi*2^64 + lo, hi < 2^32:  lo + hi*(2^32-1)
+    const uint64_t lo = a << s, hi = a >> (64 - s);
+    r = add(lo, (hi << 32) - hi);
   } else if (s < 64) {
-    // a*2^s = top*2^96 + mid*2^64 + lo  with lo = a << s (64 bits), mid:32 bits, top: s-32 bits
-    unsigned k = s - 32;                       // 0 < k < 32
-    uint64_t lo = a << s;                      // (a << s) mod 2^64
-    uint64_t h = a >> (64 - s);                // bits above 2^64: < 2^s
-    uint64_t mid = h & 0xffffffffull, top = h >> 32;  // top < 2^k
-    (void)k;
-    uint64_t t = (mid << 32) - mid;            // mid*(2^32-1)
-    r = add(lo >= P ? lo - P : lo, t);
-    r = sub(r, top);                           // 2^96 = -1
+    // a*2^s = top*2^96 + mid*2^64 + lo:  lo + mid*(2^32-1) - top
+    const uint64_t lo = a << s, h = a >> (64 - s);
+    const uint64_t mid = h & 0xffffffffull, top = h >> 32;
+    r = sub(add(lo, (mid << 32) - mid), top);
   } else if (s == 64) {
-    // a*2^64 = ah*2^96 + al*2^64 = -ah + al*(2^32-1)
-    uint64_t ah = a >> 32, al = a & 0xffffffffull;
+    const uint64_t ah = a >> 32, al = a & 0xffffffffull;
     r = sub((al << 32) - al, ah);
   } else {
-    // 64 < s < 96: a*2^s = (a*2^(s-64)) * 2^64; a*2^(s-64) = hi2*2^64 + lo2 (hi2 < 2^32)
-    unsigned k = s - 64;                       // 0 < k < 32
-    uint64_t lo2 = a << k, hi2 = a >> (64 - k);
-    // lo2*2^64 = l1*2^96 + l0*2^64 = -l1 + l0*(2^32-1);  hi2*2^128 = hi2 * 2^32 * 2^96 = -(hi2<<32)
-    uint64_t l1 = lo2 >> 32, l0 = lo2 & 0xffffffffull;
-    r = sub((l0 << 32) - l0, l1);
-    r = sub(r, hi2 << 32);                     // hi2<<32 < 2^64-2^32 < P
+    // 64 < s < 96: (a*2^k)*2^64, k = s-64: a*2^k = hi2*2^64 + l1*2^32 + l0
+    //   l0*2^64 = l0*(2^32-1);  l1*2^96 = -l1;  hi2*2^128 = -hi2*2^32
+    const unsigned k = s - 64;
+    const uint64_t lo2 = a << k, hi2 = a >> (64 - k);
+    const uint64_t l1 = lo2 >> 32, l0 = lo2 & 0xffffffffull;
+    r = sub((l0 << 32) - l0, l1 + (hi2 << 32));
   }
   return negate ? neg(r) : r;
 }

@@ -15,6 +15,7 @@
 // All kernels take the geometry in a DevPlan by value; nothing is compiled per exponent.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gf.hpp"
 #include "kernels.hpp"
@@ -149,7 +150,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 // ---------------------------------------------------------------------------------------------
 // front: one work-group per tile T (C adjacent columns, all M1 rows)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_front(DevPlan pl, const uint32_t* __restrict__ digits, uint64_t* __restrict__ Wout) {
+__global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __restrict__ digits, uint64_t* __restrict__ Wout) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
   const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) k_front(DevPlan pl, const uint32_t* __res
 // ---------------------------------------------------------------------------------------------
 // middle: one work-group per row.  mode 0: square, 1: multiply by image Y, 2: forward only.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_middle(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
+__global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
                                                 uint64_t* __restrict__ Wout, int mode) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, row = blockIdx.x, M2 = pl.M2;
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(256) k_middle(DevPlan pl, const uint64_t* __re
 // ---------------------------------------------------------------------------------------------
 // back: inverse of front + unweight + carry over the tile's M1 runs of 2C digits
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_back(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+__global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
                                               uint64_t* __restrict__ cbuf, uint32_t a) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
@@ -362,8 +363,9 @@ __global__ void k_sub_small(DevPlan pl, uint32_t* __restrict__ digits, uint32_t 
 // ------------------------------- launch wrappers ---------------------------------------------
 
 static inline uint32_t block_for(size_t work) {
+  static const size_t cap = [] { const char* e = getenv("MI355_THREADS"); size_t v = e ? size_t(atoi(e)) : 256; return v < 64 ? 64 : (v > 1024 ? 1024 : v); }();
   size_t b = 64;
-  while (b < 256 && b < work) b <<= 1;
+  while (b < cap && b < work) b <<= 1;
   return uint32_t(b);
 }
 

@@ -22,4 +22,13 @@ hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t*
 hipError_t launch_addsub(const DevPlan& pl, uint32_t* dst, const uint32_t* src, uint64_t* cbuf, int negate, hipStream_t s);
 hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hipStream_t s);
 
+
+// register-resident radix-8 set (kernels_v2.hip); shapes: rows M2 = 4096, columns M1 = 1024 x C = 4
+bool v2_rows_supported(const DevPlan& pl);
+bool v2_cols_supported(const DevPlan& pl);
+hipError_t v2_configure();
+hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s);
+hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
+hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
+
 }  // namespace mi355

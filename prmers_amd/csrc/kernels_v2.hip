@@ -1,0 +1,423 @@
+// gfx950 kernels, register-resident radix-8 set ("v2") for the large power-of-two shapes.
+//
+// Same three sweeps as kernels.hip, but each work-group of 512 threads keeps its 4096-pair tile in
+// registers (8 pairs per thread) and uses LDS only to exchange between radix-8 stages, and the stages
+// are grouped into multiplication-free 64-point blocks:
+//   * inside a block every root of unity is a power of two (omega_64 = 2^39): butterflies are add/sub
+//     plus constant shifts (gfdft.hpp), the twiddle between the two radix-8 halves of a block is a
+//     shift whose amount is uniform per wavefront (the thread->element maps below put the digit that
+//     selects it in the wave index), so it costs scalar branches, not lane divergence;
+//   * only the seam between two blocks is a general GF(P) multiplication (one per element and
+//     direction, from a universal omega_M table), against three per radix-4 level pair in the
+//     reference's schedule (marin.cl:304-318: fwd4/bck4 with r1, r23.s0, r23.s1).
+// Shapes served: rows M2 = 4096 (8.8.8.8), columns M1 = 1024 with C = 4 (2.8.8.8).  Everything else
+// runs on the generic set.  Row order of the work buffer and digit layout are those of kernels.hip,
+// so the two sets interoperate kernel by kernel (the multiplicand image layout differs: an engine
+// uses one middle kernel for both set_multiplicand and mul).
+//
+// LDS exchanges (P2 = 16 B slots, index skewed by i + i/8 against bank conflicts):
+//   writer "thread-major": slot t*8 + r          reader: slot j*512 + t'
+//   writer "wave-major":   slot w*512 + r*64 + f(lane)   reader: slot j*512 + t'
+// which is the digit permutation that hands each thread the 8 elements of its next radix-8.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gfdft.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+namespace v2 {
+
+struct alignas(16) P2 { uint64_t a, b; };
+
+__device__ __forceinline__ uint32_t phys(uint32_t i) { return i + (i >> 3); }
+constexpr uint32_t kLdsSlots = 4096 + 512;
+constexpr uint32_t kLdsBytes = kLdsSlots * 16;
+
+__device__ __forceinline__ P2 p2_mul(P2 x, uint64_t w) { return {gf::mul(x.a, w), gf::mul(x.b, w)}; }
+
+template <bool INV>
+__device__ __forceinline__ void dft8p(P2 (&x)[8]) {
+  uint64_t u[8], v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { u[j] = x[j].a; v[j] = x[j].b; }
+  gf::dft8<INV>(u);
+  gf::dft8<INV>(v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = {u[j], v[j]};
+}
+
+// x *= 2^s with s uniform over the wavefront (scalar branches inside mul_pow2)
+__device__ __forceinline__ P2 shift_uniform(P2 x, uint32_t s) {
+  s = __builtin_amdgcn_readfirstlane(s);
+  return {gf::mul_pow2(x.a, s), gf::mul_pow2(x.b, s)};
+}
+
+// omega_m^e from the two-level table (e < m)
+__device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
+  const uint64_t lo = pl.TWlo[e & ((1u << pl.twh) - 1)], hi = pl.TWhi[e >> pl.twh];
+  return gf::mul(lo, hi);
+}
+
+__device__ __forceinline__ void digit_info(const DevPlan& pl, uint32_t sa, uint32_t sb, uint32_t& width, bool& wrap) {
+  uint64_t s = uint64_t(sa) + sb;
+  wrap = (sa > 0) && (sb > 0) && (s <= pl.n);
+  if (s >= pl.n) s -= pl.n;
+  width = pl.q + ((s + pl.t > 0) ? 1u : 0u) + ((s + pl.t > pl.n) ? 1u : 0u) - ((s > 0) ? 1u : 0u);
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_v2[];
+
+// exchange helpers: barrier, write 8, barrier, read 8
+#define EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)                      \
+  __syncthreads();                                                 \
+  _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) X[phys((t) * 8 + r_)] = x[r_]; \
+  __syncthreads();                                                 \
+  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) x[j_] = X[phys(j_ * 512 + (t))];
+
+#define EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)                      \
+  __syncthreads();                                                 \
+  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) X[phys(j_ * 512 + (t))] = x[j_]; \
+  __syncthreads();                                                 \
+  _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) x[r_] = X[phys((t) * 8 + r_)];
+
+// ---------------------------------------------------------------------------------------------
+// middle, M2 = 4096 = 8.8.8.8.  Element index e = 512 d1 + 64 d2 + 8 d3 + d4.
+//   S1 thread (d2|d3|d4) regs d1 -> k1 ; shift omega_64^(k1 d2)         [d2 = wave]
+//   S2 thread (d3|d4|k1) regs d2 -> k2 ; general omega_4096^((k1+8k2)(8d3+d4))
+//   S3 thread (d4|k1|k2) regs d3 -> k3 ; shift omega_64^(k3 d4)         [d4 = wave]
+//   S4 thread (k3|k1|k2) regs d4 -> k4 ; X[k], k = k1 + 8 k2 + 64 k3 + 512 k4
+// pointwise in registers, then the mirror image back to natural order.
+// mode 0: square, 1: multiply by image Y, 2: forward only (writes the image).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
+                                                      uint64_t* __restrict__ Wout, int mode) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), row = blockIdx.x;
+  const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 4096;
+  P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * 4096;
+  const uint64_t* __restrict__ UT = pl.UT2;   // omega_4096^e
+  P2 x[8];
+
+  // ---- forward ----
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = in[512 * j + t];
+  dft8p<false>(x);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (gf::LOG2_W64 * k * wave) % 192);
+  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  dft8p<false>(x);
+  {
+    const uint32_t k1 = t & 7, b = t >> 3;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const uint32_t e = (k1 + 8 * k2) * b;
+      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], UT[e]);
+    }
+  }
+  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  dft8p<false>(x);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (gf::LOG2_W64 * k * wave) % 192);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) X[phys(wave * 512 + k * 64 + lane)] = x[k];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = X[phys(j * 512 + t)];
+  dft8p<false>(x);
+
+  if (mode == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
+    return;
+  }
+
+  // ---- pointwise: reg k4 holds X[kb + 512 k4]; rho = omega_m^(k1row + M1 k) = rho0 * omega_8^k4 ----
+  {
+    const uint32_t kb = (lane >> 3) + 8 * (lane & 7) + 64 * wave;
+    // column-DFT slot -> frequency (same map as kernels.hip freq1; this kernel is used with r5 == 1 or 5)
+    const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;
+    const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+    const uint64_t rho0 = tw_lookup(pl, uint64_t(k1row) + uint64_t(pl.M1) * kb);
+    const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * 4096;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      // omega_8^k4 = 2^(120 k4): +1, -2^24, +2^48, -2^72, -1, +2^24, -2^48, +2^72
+      const unsigned sh = 24u * (k4 & 3);
+      const bool neg = (k4 == 1) || (k4 == 3) || (k4 == 4) || (k4 == 6);
+      const P2 u = x[k4];
+      P2 r;
+      if (mode == 0) {   // (u0 + u1 t)^2 mod (t^2 - rho), marin.cl:379-384
+        const uint64_t q = gf::mul_pow2(gf::mul(gf::sqr(u.b), rho0), sh);
+        const uint64_t s0 = gf::sqr(u.a);
+        r.a = neg ? gf::sub(s0, q) : gf::add(s0, q);
+        r.b = gf::mul(u.b, gf::dbl(u.a));
+      } else {           // marin.cl:387-392
+        const P2 y = Y[512 * k4 + t];
+        const uint64_t q = gf::mul_pow2(gf::mul(gf::mul(u.b, y.b), rho0), sh);
+        const uint64_t s0 = gf::mul(u.a, y.a);
+        r.a = neg ? gf::sub(s0, q) : gf::add(s0, q);
+        r.b = gf::add(gf::mul(u.a, y.b), gf::mul(u.b, y.a));
+      }
+      x[k4] = r;
+    }
+  }
+
+  // ---- inverse (mirror) ----
+  dft8p<true>(x);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) X[phys(j * 512 + t)] = x[j];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = X[phys(wave * 512 + k * 64 + lane)];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (192 - (gf::LOG2_W64 * k * wave) % 192) % 192);
+  dft8p<true>(x);
+  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+  {
+    const uint32_t k1 = t & 7, b = t >> 3;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const uint32_t e = (k1 + 8 * k2) * b;
+      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], UT[(4096 - e) & 4095]);
+    }
+  }
+  dft8p<true>(x);
+  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+#pragma unroll
+  for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (192 - (gf::LOG2_W64 * k * wave) % 192) % 192);
+  dft8p<true>(x);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
+}
+
+// previous run (in digit order) of run (T, i1); see kernels.hip
+__device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_t* cbuf, uint32_t T, uint32_t i1) {
+  const uint32_t NT = pl.M2 / pl.C;
+  if (T > 0) return cbuf[size_t(T - 1) * pl.M1 + i1];
+  return cbuf[size_t(NT - 1) * pl.M1 + (i1 ? i1 - 1 : pl.M1 - 1)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// front, M1 = 1024 = 2.8.8.8, C = 4.  Tile element (i1, c), i1 = 512 d1 + 64 d2 + 8 d3 + d4.
+//   S1 thread (d2|d3|d4) regs (d1,c): two whole runs of 8 digits -> weight -> DFT2 -> k1 ; shift omega_16^(k1 d2)
+//   S2 thread (d3|d4|k1|c) regs d2 -> k2 ; general omega_1024^((k1+2k2)(8d3+d4))
+//   S3 thread (d4|k1|c|k2) regs d3 -> k3 ; shift omega_64^(k3 d4)
+//   S4 thread (k3|k1|k2|c) regs d4 -> k4 ; k1col = k1 + 2 k2 + 16 k3 + 128 k4
+//   then the four-step twiddle omega_m^(i2 k1col) * TB (geometric in k4: one chain multiply per element)
+//   and the store to work-buffer row bitrev10(k1col), column i2 = 4T + c.
+// cbuf_in (nullable): pending run carries of this register (deferred k_carry_fix); sub: pending
+// small subtraction at digit 0 (LL's x^2 - 2), applied in the field.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 4) k1_cols1024x4(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
+                                                        uint32_t sub, uint64_t* __restrict__ Wout) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
+  P2 x[8];
+
+#pragma unroll
+  for (int d1 = 0; d1 < 2; ++d1) {
+    const uint32_t i1 = 512 * d1 + t;
+    const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * 1024 + i1) * 2;
+    const uint4 q0 = src[0], q1 = src[1];
+    uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    const uint32_t sa = pl.SA[i1];
+    const uint64_t ta = pl.TA[i1];
+    uint32_t width[8]; bool wrap[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) digit_info(pl, sa, pl.SB[8 * T + k], width[k], wrap[k]);
+    if (cbuf_in) {   // weak carry of the previous run's carry word (adc4, marin.cl:203-212)
+      uint64_t cin = carry_in_of(pl, cbuf_in, T, i1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const uint64_t v = uint64_t(d[k]) + cin;
+        d[k] = uint32_t(v & ((uint64_t(1) << width[k]) - 1));
+        cin = v >> width[k];
+      }
+      d[3] += uint32_t(cin);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint64_t a0 = gf::mul_u32(ta, d[2 * c]), a1 = gf::mul_u32(ta, d[2 * c + 1]);
+      if (wrap[2 * c]) a0 = gf::half(a0);
+      if (wrap[2 * c + 1]) a1 = gf::half(a1);
+      x[4 * d1 + c] = {a0, a1};
+    }
+    if (sub != 0 && T == 0 && i1 == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));   // digit 0 has weight 1
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const P2 u = x[c], v = x[4 + c];
+    x[c] = {gf::add(u.a, v.a), gf::add(u.b, v.b)};
+    x[4 + c] = {gf::sub(u.a, v.a), gf::sub(u.b, v.b)};
+  }
+  {
+    const uint32_t s = (4 * gf::LOG2_W64 * wave) % 192;   // omega_16^d2 = omega_64^(4 d2)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[4 + c] = shift_uniform(x[4 + c], s);
+  }
+  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  dft8p<false>(x);
+  {
+    const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const uint32_t e = (k1 + 2 * k2) * b;   // < 16 * 64
+      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], pl.UT1[e]);
+    }
+  }
+  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  dft8p<false>(x);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (gf::LOG2_W64 * k * wave) % 192);
+  {
+    // lane = k1*32 + c*8 + k2  ->  slot offset k1*32 + k2*4 + c
+    const uint32_t off = (lane & 32) | ((lane & 7) << 2) | ((lane >> 3) & 3);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) X[phys(wave * 512 + k * 64 + off)] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = X[phys(j * 512 + t)];
+  }
+  dft8p<false>(x);
+  {
+    const uint32_t c = t & 3, k2 = (t >> 2) & 7, k1 = (t >> 5) & 1, k3 = t >> 6;
+    const uint32_t kb = k1 + 2 * k2 + 16 * k3;
+    const uint32_t i2 = 4 * T + c;
+    const uint64_t A = tw_lookup(pl, (uint64_t(i2) * kb) % pl.m);
+    const uint64_t B = tw_lookup(pl, (uint64_t(i2) * 128) % pl.m);
+    uint64_t ca = gf::mul(A, pl.TB[2 * i2]), cb = gf::mul(A, pl.TB[2 * i2 + 1]);
+    const uint32_t row0 = __brev(kb) >> 22;   // bitrev10(kb): low 3 bits are zero
+    P2* W = reinterpret_cast<P2*>(Wout);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t rj = ((j & 1) << 2) | (j & 2) | (j >> 2);   // bitrev3(j)
+      W[size_t(row0 + rj) * pl.M2 + i2] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, cb)};
+      if (j < 7) { ca = gf::mul(ca, B); cb = gf::mul(cb, B); }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// back: mirror of front, then unweight and carry each of the thread's two runs sequentially.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+                                                        uint64_t* __restrict__ cbuf, uint32_t a) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
+  P2 x[8];
+  {
+    const uint32_t c = t & 3, k2 = (t >> 2) & 7, k1 = (t >> 5) & 1, k3 = t >> 6;
+    const uint32_t kb = k1 + 2 * k2 + 16 * k3;
+    const uint32_t i2 = 4 * T + c;
+    const uint64_t ea = (uint64_t(i2) * kb) % pl.m, eb = (uint64_t(i2) * 128) % pl.m;
+    const uint64_t A = tw_lookup(pl, ea ? pl.m - ea : 0);
+    const uint64_t B = tw_lookup(pl, eb ? pl.m - eb : 0);
+    uint64_t ca = gf::mul(A, pl.TBi[2 * i2]), cb = gf::mul(A, pl.TBi[2 * i2 + 1]);
+    const uint32_t row0 = __brev(kb) >> 22;
+    const P2* W = reinterpret_cast<const P2*>(Win);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t rj = ((j & 1) << 2) | (j & 2) | (j >> 2);
+      x[j] = W[size_t(row0 + rj) * pl.M2 + i2];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[j] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, cb)};
+      if (j < 7) { ca = gf::mul(ca, B); cb = gf::mul(cb, B); }
+    }
+  }
+  dft8p<true>(x);
+  {
+    const uint32_t off = (lane & 32) | ((lane & 7) << 2) | ((lane >> 3) & 3);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) X[phys(j * 512 + t)] = x[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = X[phys(wave * 512 + k * 64 + off)];
+  }
+#pragma unroll
+  for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (192 - (gf::LOG2_W64 * k * wave) % 192) % 192);
+  dft8p<true>(x);
+  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+  {
+    const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const uint32_t e = (k1 + 2 * k2) * b;
+      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], pl.UT1[(1024 - e) & 1023]);
+    }
+  }
+  dft8p<true>(x);
+  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+  {
+    const uint32_t s = (192 - (4 * gf::LOG2_W64 * wave) % 192) % 192;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[4 + c] = shift_uniform(x[4 + c], s);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const P2 u = x[c], v = x[4 + c];
+    x[c] = {gf::add(u.a, v.a), gf::add(u.b, v.b)};
+    x[4 + c] = {gf::sub(u.a, v.a), gf::sub(u.b, v.b)};
+  }
+
+#pragma unroll
+  for (int d1 = 0; d1 < 2; ++d1) {
+    const uint32_t i1 = 512 * d1 + t;
+    const uint32_t sa = pl.SA[i1];
+    const uint64_t tai = pl.TAi[i1];
+    uint64_t carry = 0;
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t width; bool wrap;
+      digit_info(pl, sa, pl.SB[8 * T + k], width, wrap);
+      const P2 v = x[4 * d1 + (k >> 1)];
+      uint64_t u = gf::mul((k & 1) ? v.b : v.a, tai);
+      if (wrap) u = gf::dbl(u);
+      const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
+      const uint64_t dlo = u & mask, chi = u >> width;
+      const uint64_t r = dlo * a + carry;
+      o[k] = uint32_t(r & mask);
+      carry = (r >> width) + chi * a;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(digits) + (size_t(T) * 1024 + i1) * 2;
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    cbuf[size_t(T) * 1024 + i1] = carry;
+  }
+}
+
+}  // namespace v2
+
+// ------------------------------- launch wrappers ---------------------------------------------
+
+bool v2_rows_supported(const DevPlan& pl) { return pl.M2 == 4096; }
+bool v2_cols_supported(const DevPlan& pl) { return pl.M1 == 1024 && pl.r5 == 1 && pl.C == 4; }
+
+hipError_t v2_configure() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k1_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k3_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+}
+hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(v2::k2_rows4096, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, mode);
+  return hipGetLastError();
+}
+hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
+  hipLaunchKernelGGL(v2::k1_cols1024x4, dim3(pl.M2 / 4), dim3(512), v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
+  return hipGetLastError();
+}
+hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s) {
+  hipLaunchKernelGGL(v2::k3_cols1024x4, dim3(pl.M2 / 4), dim3(512), v2::kLdsBytes, s, pl, W, digits, cbuf, a);
+  return hipGetLastError();
+}
+
+}  // namespace mi355

@@ -29,6 +29,8 @@ SMALL_CASES = [
     (933, None), (933, "m2=2,c=2"), (1801, "m2=8,c=4"), (1801, "m2=4,c=4"), (3997, "m2=16,c=4"), (3997, None),
     (9941, None), (9941, "m2=16,c=4"), (9941, "m2=64,c=8"), (9941, "m2=4,c=4"), (9941, "m2=128,c=2"),
     (13967, None), (13967, "m2=16,c=8"), (44497, None), (44497, "m2=32,c=4"), (102701, None), (102701, "m2=64,c=2"),
+    # shapes served by the register-resident radix-8 kernels: rows of 4096, columns of 1024 x 4
+    (300007, "m2=4096"), (300007, "m2=8,c=4"), (216091, None),
 ]
 
 
@@ -140,7 +142,7 @@ def test_reg_adapter_contract():
 
 
 @pytest.mark.parametrize("p,plan", [(127, None), (1279, None), (9941, "m2=16,c=4"), (3997, None), (3997, "m2=4,c=2"),
-                                    (86243, None), (216091, None)])
+                                    (86243, None), (216091, None), (300007, "m2=4096"), (300007, "m2=8,c=4")])
 def test_ops_random_vs_bigint_and_oracle(p, plan):
     M = (1 << p) - 1
     rng = np.random.default_rng(p)
@@ -226,3 +228,53 @@ def test_c2_9815459_first_iterations():
             e.square_mul(0); o.square_mul(0)
             if it in (0, 20, 40, 59):
                 assert np.array_equal(e.digits(0), o.digits(0)), it
+
+
+def test_c3_136279841_full_size():
+    """BASELINE config C3 (n = 2^23, both radix-8 kernels in use): squarings, the LL step x^2-2, mul and
+    the Gerbicz identity against the oracle's digit vectors."""
+    p = 136279841
+    o = orc.Oracle(p, 3)
+    rng = np.random.default_rng(5)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 4) as e:
+        assert e.n == 1 << 23
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        for it in range(3):
+            e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.square_mul(0, 3); o.square_mul(0, 3)
+        e.sub(0, 2); o.sub(0, 2)                       # LL step with the subtraction deferred into the next sweep
+        e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.copy(1, 0); o.copy(1, 0)
+        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)
+        e.mul(0, 2); o.mul(0, 2)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert e.res64(0) == o.res64(0)
+
+
+def test_full_size_properties_no_oracle():
+    """size-independent identities at n = 2^23: (x*y)^2 == x^2 * y^2 and (x+y)^2 - x^2 - y^2 == 2xy."""
+    p = 136279841
+    rng = np.random.default_rng(11)
+    with Engine(p, 8) as e:
+        n = e.n
+        dig = lambda: e.digits(0) * 0   # noqa: E731
+        base = e.digits(7)              # widths (register 7 is zero)
+        w = base >> np.uint64(32)
+        for r in (0, 1):
+            e.set_digits(r, (rng.integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32)))
+        # (x*y)^2
+        e.copy(2, 0); e.set_multiplicand(3, 1); e.mul(2, 3); e.square_mul(2)
+        # x^2 * y^2
+        e.copy(4, 0); e.square_mul(4); e.copy(5, 1); e.square_mul(5); e.set_multiplicand(6, 5); e.mul(4, 6)
+        assert e.is_equal(2, 4)
+        # (x+y)^2 - x^2 - y^2 == 2xy
+        e.copy(2, 0); e.add(2, 1); e.square_mul(2)
+        e.copy(4, 0); e.square_mul(4); e.sub_reg(2, 4)
+        e.copy(4, 1); e.square_mul(4); e.sub_reg(2, 4)
+        e.copy(4, 0); e.mul(4, 3, 2)
+        assert e.is_equal(2, 4)
