@@ -363,7 +363,7 @@ __global__ void k_sub_small(DevPlan pl, uint32_t* __restrict__ digits, uint32_t 
 // ------------------------------- launch wrappers ---------------------------------------------
 
 static inline uint32_t block_for(size_t work) {
-  static const size_t cap = [] { const char* e = getenv("MI355_THREADS"); size_t v = e ? size_t(atoi(e)) : 256; return v < 64 ? 64 : (v > 1024 ? 1024 : v); }();
+  static const size_t cap = [] { const char* e = getenv("MI355_THREADS"); size_t v = e ? size_t(atoi(e)) : 512; return v < 64 ? 64 : (v > 1024 ? 1024 : v); }();
   size_t b = 64;
   while (b < cap && b < work) b <<= 1;
   return uint32_t(b);

@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355_engine.so")
+# MI355_ENGINE_LIB overrides the library path (A/B builds), as AEVUM_ENGINE_LIB does for the reference's plugin
+# (src/aevum/EngineAevum.cpp:193-223)
+LIB_PATH = os.environ.get("MI355_ENGINE_LIB") or os.path.join(_HERE, "libmi355_engine.so")
 
 
 class EngineError(RuntimeError):

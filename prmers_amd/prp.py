@@ -1,0 +1,257 @@
+"""PRP / Lucas-Lehmer drivers over the `engine` register machine -- the callers of the hot path.
+
+Mirror of the reference's Marin-path driver (src/modes/RunPrpOrLlMarin.cpp:97-777): base-3 PRP with
+the Gerbicz-Li check and rollback (:338-412), the `-erroriter` fault injection (:326-336), LL-unsafe
+(x^2-2, :321-324), checkpoint files (:156-211 with the CRC of include/marin/file.h:49-111), result
+formatting (include/core/AlgoUtils.hpp:165-223) and the worktodo line formats
+(src/io/WorktodoParser.cpp:78-400) used to shard exponents one per GPU.
+
+Everything here talks to an engine only through its interface (set / copy / square_mul / sub /
+set_multiplicand / mul / get_int / digits / get_checkpoint / set_checkpoint), so the same driver runs
+on prmers_amd.Engine (MI355X) and, in the CPU tests, on an oracle-backed stand-in.
+"""
+import math
+import os
+import struct
+import zlib
+
+import numpy as np
+
+# register roles of the reference driver (RunPrpOrLlMarin.cpp:212)
+R0, R1, R2, R3, R4, R5, RBASE, RTMP = range(8)
+REGISTERS = 8
+CKPT_BACKEND_ID = 3      # 1 = Marin/OpenCL, 2 = Aevum (RunPrpOrLlMarin.cpp:154); images are backend-specific
+
+
+# ---------------------------------------------------------------------------------------------
+# residue formatting (AlgoUtils.hpp:165-223, engine.h:257-295)
+# ---------------------------------------------------------------------------------------------
+def pack_words(digits, p):
+    """little-endian 32-bit words of an encoded digit vector (value | width << 32)."""
+    v, s = 0, 0
+    for x in np.asarray(digits, dtype=np.uint64).tolist():
+        w = x >> 32
+        v |= (x & ((1 << w) - 1) & 0xFFFFFFFF) << s
+        s += w
+    wc = (p + 31) // 32
+    return np.frombuffer((v & ((1 << (32 * wc)) - 1)).to_bytes(wc * 4, "little"), dtype="<u4").copy()
+
+
+def _div3_words(p, W):
+    r = (3 - int(sum(int(w) % 3 for w in W) % 3)) % 3
+    top = p % 32
+    t = (r << top) + int(W[-1])
+    W[-1], r = t // 3, t % 3
+    for i in range(len(W) - 2, -1, -1):
+        t = (r << 32) + int(W[i])
+        W[i], r = t // 3, t % 3
+
+
+def prp3_div9(p, W):
+    """type-1 residue: divide 3^(2^p) by 9 mod 2^p-1 on the word vector (AlgoUtils.hpp:204-210)."""
+    W = [int(w) for w in W]
+    _div3_words(p, W)
+    _div3_words(p, W)
+    return np.array(W, dtype=np.uint64).astype("<u4")
+
+
+def format_res64(W):
+    return "%016X" % ((int(W[1]) << 32 if len(W) > 1 else 0) | (int(W[0]) if len(W) else 0))
+
+
+def format_res2048(W):
+    return "".join("%08x" % (int(W[i]) if i < len(W) else 0) for i in range(63, -1, -1))
+
+
+def digits_equal_to(digits, a):
+    r = a
+    for x in np.asarray(digits, dtype=np.uint64).tolist():
+        w = x >> 32
+        if (r & ((1 << w) - 1)) != (x & 0xFFFFFFFF):
+            return False
+        r >>= w
+    return True
+
+
+def digits_equal_to_Mp(digits):
+    d = np.asarray(digits, dtype=np.uint64)
+    w = d >> np.uint64(32)
+    return bool(np.all((d & np.uint64(0xFFFFFFFF)) == (np.uint64(1) << w) - np.uint64(1)))
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint file: version 2 layout of RunPrpOrLlMarin.cpp:190-206, CRC trailer of file.h:98-111
+# ---------------------------------------------------------------------------------------------
+def checkpoint_name(p, mode, directory="."):
+    return os.path.join(directory, ("llunsafe_" if mode == "ll" else "") + "m_%d.ckpt" % p)
+
+
+def save_checkpoint(path, eng, p, mode, it, elapsed):
+    data = np.asarray(eng.get_checkpoint(), dtype=np.uint8).tobytes()
+    body = struct.pack("<iIIIId", 2, p, 1 if mode == "prp" else 2, CKPT_BACKEND_ID, it, elapsed) + data
+    crc = zlib.crc32(body) & 0xFFFFFFFF
+    trailer = struct.pack("<I", (~crc & 0xFFFFFFFF) ^ 0xA23777AC)
+    new, old = path + ".new", path + ".old"
+    with open(new, "wb") as f:
+        f.write(body + trailer)
+    if os.path.exists(old):
+        os.remove(old)
+    if os.path.exists(path):
+        os.rename(path, old)
+    os.rename(new, path)
+
+
+def load_checkpoint(path, eng, p, mode):
+    """-> (iter, elapsed) or None (missing / other exponent, mode or backend / bad CRC)."""
+    try:
+        raw = open(path, "rb").read()
+    except OSError:
+        return None
+    head = struct.calcsize("<iIIIId")
+    if len(raw) < head + 4:
+        return None
+    version, rp, smode, sbackend, it, elapsed = struct.unpack("<iIIIId", raw[:head])
+    if version != 2 or rp != p or smode != (1 if mode == "prp" else 2) or sbackend != CKPT_BACKEND_ID:
+        return None
+    body, trailer = raw[:-4], struct.unpack("<I", raw[-4:])[0]
+    if trailer != ((~zlib.crc32(body) & 0xFFFFFFFF) ^ 0xA23777AC):
+        return None
+    data = np.frombuffer(body[head:], dtype=np.uint8)
+    if data.size != eng.get_checkpoint_size() or not eng.set_checkpoint(data):
+        return None
+    return it, elapsed
+
+
+# ---------------------------------------------------------------------------------------------
+# worktodo (WorktodoParser.cpp:78-400): only what the one-exponent-per-GPU sharder needs
+# ---------------------------------------------------------------------------------------------
+def parse_worktodo_line(line):
+    """-> (mode, exponent) for PRP= / PRPDC= / Test= / DoubleCheck= lines, else None."""
+    line = line.strip()
+    if not line or line[0] == "#" or "=" not in line:
+        return None
+    key, rest = line.split("=", 1)
+    key = key.strip().upper()
+    if key in ("PRP", "PRPDC"):
+        mode = "prp"
+    elif key in ("TEST", "DOUBLECHECK"):
+        mode = "ll"
+    else:
+        return None
+    parts = [x.strip() for x in rest.split(",")]
+    if parts and (parts[0] == "" or parts[0] == "N/A"):
+        parts = parts[1:]
+    if parts and (parts[0] in ("AID", "N/A") or (len(parts[0]) == 32 and all(c in "0123456789abcdefABCDEF" for c in parts[0]))):
+        parts = parts[1:]
+    if len(parts) >= 4 and parts[0] == "1" and parts[1] == "2" and parts[3] == "-1":
+        return mode, int(parts[2])           # k,b,n,c form: 1*2^n-1
+    if mode == "ll" and parts and parts[0].isdigit():
+        return mode, int(parts[0])           # Test=exponent[,how_far_factored[,pm1]]
+    return None
+
+
+def shard_worktodo(lines, rank, world):
+    """entries handled by `rank`: line i -> GPU i mod world."""
+    entries = [e for e in (parse_worktodo_line(l) for l in lines) if e]
+    return entries[rank::world]
+
+
+# ---------------------------------------------------------------------------------------------
+# the driver
+# ---------------------------------------------------------------------------------------------
+def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, max_iters=None,
+                  log=None, ckpt_path=None, backup_every=0):
+    """One PRP (mode "prp") or LL-unsafe (mode "ll") test of 2^p-1 on `eng` (>= 8 registers).
+
+    Returns a dict: is_prime, res64, res2048, iterations, gerbicz_checks, gerbicz_errors, complete.
+    max_iters stops early (complete = False) for partial runs; the result fields then describe the
+    residue reached.  log(msg) receives the reference's messages ("[Gerbicz Li] Check passed! iter=N").
+    """
+    log = log or (lambda m: None)
+    prp = mode == "prp"
+    total = p if prp else p - 2
+    ri = 0
+    if ckpt_path:
+        got = load_checkpoint(ckpt_path, eng, p, mode) or load_checkpoint(ckpt_path + ".old", eng, p, mode)
+        if got:
+            ri = got[0]
+            log("Resuming from a checkpoint.")
+    if ri == 0:
+        eng.set(R1, 1)
+        eng.set(R0, 3 if prp else 4)
+    eng.copy(R4, R0)          # last state that passed a check
+    eng.copy(R5, R1)
+    eng.set(RBASE, 3)
+    eng.set_multiplicand(RTMP, RBASE)
+
+    B = max(int(math.sqrt(p)), 1)
+    auto = int((1000 * 600.0) / B)
+    if auto == 0:
+        auto = (total // B) // max(int(math.sqrt(B)), 1)
+    checkpasslevel = checklevel if checklevel > 0 else max(auto, 1)
+    itersave, jsave = 0, total - 1
+    checkpass = 0
+    errordone = False
+    checks = errors = 0
+    done = 0
+    it, j = ri, total - ri - 1
+    while it < total:
+        if max_iters is not None and done >= max_iters:
+            break
+        eng.square_mul(R0)
+        if not prp:
+            eng.sub(R0, 2)
+        done += 1
+        if erroriter > 0 and it + 1 == erroriter and not errordone:
+            errordone = True
+            eng.sub(R0, 2)
+            log("Injected error at iteration %d" % (it + 1))
+        if prp and gerbicz and ((j != 0 and j % B == 0) or it == total - 1):
+            checkpass += 1
+            eng.copy(R3, R1)
+            eng.set_multiplicand(R2, R0)
+            eng.mul(R1, R2)
+            if not (checkpass != checkpasslevel and it != total - 1):
+                checkpass = 0
+                checks += 1
+                modB = B if p % B == 0 else p % B
+                for _ in range(B - modB - 1 if B > modB else 0):
+                    eng.square_mul(R3)
+                if p % B == 0:
+                    eng.mul(R3, RTMP)
+                else:
+                    eng.square_mul(R3, 3)
+                for _ in range(modB):
+                    eng.square_mul(R3)
+                if eng.get_int(R3) != eng.get_int(R1):
+                    log("[Gerbicz Li] Mismatch")
+                    log("[Gerbicz Li] Check FAILED! iter=%d" % (it + 1))
+                    log("[Gerbicz Li] Restore iter=%d (j=%d)" % (itersave, jsave))
+                    j, it = jsave, itersave
+                    if it == 0:
+                        it -= 1
+                        j += 1
+                    errors += 1
+                    eng.copy(R0, R4)
+                    eng.copy(R1, R5)
+                else:
+                    log("[Gerbicz Li] Check passed! iter=%d" % (it + 1))
+                    eng.copy(R4, R0)
+                    eng.copy(R5, R1)
+                    itersave, jsave = it, j
+        if ckpt_path and backup_every and done % backup_every == 0:
+            save_checkpoint(ckpt_path, eng, p, mode, it + 1, 0.0)
+        it += 1
+        j -= 1
+
+    d = eng.digits(R0)
+    if prp:
+        is_prime = digits_equal_to(d, 9)
+    else:
+        is_prime = digits_equal_to(d, 0) or digits_equal_to_Mp(d)
+    words = pack_words(d, p)
+    if prp and pow(2, p, 9) != 1:      # 2^p-1 not divisible by 9 (RunPrpOrLlMarin.cpp:288-291,456)
+        words = prp3_div9(p, words)
+    return {"exponent": p, "mode": mode, "is_prime": bool(is_prime) and it >= total, "res64": format_res64(words),
+            "res2048": format_res2048(words), "iterations": it, "gerbicz_checks": checks,
+            "gerbicz_errors": errors, "complete": it >= total}

@@ -194,3 +194,46 @@ def prp_type1_hex(d, p):
     L.orc_format_res64(_ptr(w), w.size, b64)
     L.orc_format_res2048(_ptr(w), w.size, b2048)
     return b64.value.decode(), b2048.value.decode()
+
+
+class OracleEngine:
+    """The oracle behind the interface of prmers_amd.Engine, so that host-side callers (prmers_amd.prp)
+    can be tested without a GPU.  Test infrastructure only."""
+
+    def __init__(self, p, reg_count=8):
+        self.o = Oracle(p, reg_count)
+        self.p, self.n, self.reg_count = p, self.o.n, reg_count
+        self.word_count = (p + 31) // 32
+
+    def close(self): self.o.close()
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+    def get_size(self): return self.n
+    def sync(self): pass
+    def set(self, dst, a): self.o.set(dst, a)
+    def copy(self, dst, src): self.o.copy(dst, src)
+    def square_mul(self, src, a=1): self.o.square_mul(src, a)
+    def set_multiplicand(self, dst, src): self.o.set_multiplicand(dst, src)
+    def mul(self, dst, src, a=1): self.o.mul(dst, src, a)
+    def sub(self, src, a): self.o.sub(src, a)
+    def add(self, dst, src): self.o.add(dst, src)
+    def sub_reg(self, dst, src): self.o.sub_reg(dst, src)
+    def digits(self, src): return self.o.digits(src)
+    def res64(self, src): return self.o.res64(src)
+    def get_int(self, src): return self.o.value(src)
+    def set_int(self, dst, v): self.o.set_value(dst, v)
+    def is_equal(self, a, b): return self.o.value(a) == self.o.value(b)
+    def get_checkpoint_size(self): return self.reg_count * self.n * 8
+
+    def get_checkpoint(self):
+        return np.concatenate([self.o.raw(r) for r in range(self.reg_count)]).view(np.uint8)
+
+    def set_checkpoint(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        if buf.size != self.get_checkpoint_size():
+            return False
+        x = buf.view(np.uint64)
+        for r in range(self.reg_count):
+            part = np.ascontiguousarray(x[r * self.n:(r + 1) * self.n])
+            self.o.L.orc_set_raw(self.o.h, r, _ptr(part))
+        return True

@@ -58,3 +58,35 @@ def test_c_abi_exports_and_no_gpu_behaviour():
     if not torch.cuda.is_available():
         with pytest.raises(E.EngineError, match="no CPU fallback|HIP"):
             E.Engine(127, 2)
+
+
+def _build_adapter(td):
+    exe = os.path.join(td, "t_adapter")
+    gmp = "/usr/lib/x86_64-linux-gnu/libgmp.so.10"
+    inc = [i for i in ("/opt/conda/include", "/usr/include") if os.path.exists(os.path.join(i, "gmp.h"))]
+    if not inc or not os.path.exists(gmp):
+        pytest.skip("gmp headers/library not available")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + inc[0], "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "test_engine_adapter.cpp"), "-ldl", gmp])
+    return exe
+
+
+def test_cpp_adapter_builds_and_binds_every_symbol():
+    """include/mi355/engine_hip.h compiles against the engine interface and dlsym-binds the C ABI."""
+    from prmers_amd import engine as E
+    if not os.path.exists(E.LIB_PATH):
+        pytest.skip("libmi355_engine.so not built")
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_adapter(td)
+        out = subprocess.run([exe, "load", E.LIB_PATH], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_adapter_reg_contract_on_gpu():
+    """tests/test_aevum_reg_adapter.cpp:32-93 through engine_hip on the MI355X."""
+    from prmers_amd import engine as E
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_adapter(td)
+        out = subprocess.run([exe, "run", E.LIB_PATH], capture_output=True, text=True)
+        assert out.returncode == 0 and "passed" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,133 @@
+"""The PRP / LL driver (prmers_amd/prp.py), i.e. the caller side of the hot path: Gerbicz-Li check,
+fault injection and rollback, checkpoints, worktodo sharding.  CPU tests drive it over the oracle;
+the GPU tests drive the very same code over the HIP engine."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from prmers_amd import prp
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+def make_engine(kind, p):
+    if kind == "gpu":
+        from prmers_amd import Engine
+        return Engine(p, prp.REGISTERS)
+    return orc.OracleEngine(p, prp.REGISTERS)
+
+
+KINDS = ["oracle", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("p", [127, 521, 1279])
+def test_prp_prime_with_gerbicz(kind, p):
+    msgs = []
+    with make_engine(kind, p) as e:
+        r = prp.run_prp_or_ll(e, p, "prp", log=msgs.append, checklevel=1)
+    assert r["is_prime"] and r["complete"] and r["res64"] == "0000000000000001"
+    assert r["gerbicz_errors"] == 0 and r["gerbicz_checks"] >= 1
+    assert any(m.startswith("[Gerbicz Li] Check passed!") for m in msgs)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("p,prime", [(127, True), (521, True), (1001, False), (607, True), (91, False)])
+def test_ll_unsafe(kind, p, prime):
+    """x -> x^2 - 2 from 4, p-2 iterations, prime iff 0 or Mp (RunPrpOrLlMarin.cpp:245,321-324,449-450)."""
+    with make_engine(kind, p) as e:
+        r = prp.run_prp_or_ll(e, p, "ll")
+    s, M = 4, (1 << p) - 1
+    for _ in range(p - 2):
+        s = (s * s - 2) % M
+    assert r["is_prime"] == prime == (s == 0)
+    if prime:   # 0 may come out as the all-ones vector 2^p-1 (engine.h:286-295; RunPrpOrLlMarin.cpp:449-450)
+        assert r["res64"] in ("0" * 16, "F" * 16)
+    else:
+        assert r["res64"] == "%016X" % (s & (2**64 - 1))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("erroriter", GOLD["gerbicz_error_injection"]["erroriters"])
+def test_gerbicz_error_injection_golden(kind, erroriter):
+    """unit_tests.sh:24-50: `prmers 9941 -erroriter N` must print the failed check at iter 9941, restore
+    iter=0 (j=9940), and still finish with the right answer."""
+    g = GOLD["gerbicz_error_injection"]
+    msgs = []
+    with make_engine(kind, g["p"]) as e:
+        r = prp.run_prp_or_ll(e, g["p"], "prp", erroriter=erroriter, log=msgs.append)
+    assert "Injected error at iteration %d" % erroriter in msgs
+    assert "[Gerbicz Li] Check FAILED! iter=%d" % g["failed_at_iter"] in msgs
+    assert "[Gerbicz Li] Restore iter=%d (j=%d)" % (g["restore_iter"], g["restore_j"]) in msgs
+    assert r["gerbicz_errors"] == 1 and r["is_prime"] and r["complete"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_m11213_type1_residue(kind):
+    with make_engine(kind, 11213) as e:
+        r = prp.run_prp_or_ll(e, 11213, "prp")
+    assert r["is_prime"] and r["res64"] == GOLD["m11213_final"]["res64"] and r["res2048"] == "0" * 511 + "1"
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_checkpoint_roundtrip_and_resume(kind, tmp_path):
+    p = 1279
+    path = prp.checkpoint_name(p, "prp", str(tmp_path))
+    with make_engine(kind, p) as e:
+        part = prp.run_prp_or_ll(e, p, "prp", max_iters=700, ckpt_path=path, backup_every=100, gerbicz=False)
+        assert not part["complete"] and part["iterations"] == 700
+    assert os.path.exists(path) and os.path.exists(path + ".old")
+    with make_engine(kind, p) as e:
+        msgs = []
+        r = prp.run_prp_or_ll(e, p, "prp", ckpt_path=path, gerbicz=False, log=msgs.append)
+    assert "Resuming from a checkpoint." in msgs and r["is_prime"] and r["complete"]
+    # corrupt -> ignored (file.h:104-111), other mode -> ignored (RunPrpOrLlMarin.cpp:166-170)
+    raw = bytearray(open(path, "rb").read()); raw[40] ^= 1; open(path, "wb").write(bytes(raw))
+    with make_engine(kind, p) as e:
+        assert prp.load_checkpoint(path, e, p, "prp") is None
+        assert prp.load_checkpoint(path + ".old", e, p, "ll") is None
+        assert prp.load_checkpoint(path + ".old", e, p, "prp") is not None
+
+
+def test_worktodo_parsing_and_sharding():
+    lines = ["# comment", "PRP=1,2,136279841,-1", "PRP=0123456789ABCDEF0123456789ABCDEF,1,2,136279879,-1,76,0",
+             "Test=136279901", "DoubleCheck=0123456789abcdef0123456789abcdef,85473391,76,1", "Test=1,2,127,-1",
+             "PFactor=1,2,100003,-1,70,2", "garbage", "PRPDC=N/A,1,2,521,-1"]
+    got = [prp.parse_worktodo_line(l) for l in lines]
+    assert got == [None, ("prp", 136279841), ("prp", 136279879), ("ll", 136279901), ("ll", 85473391), ("ll", 127),
+                   None, None, ("prp", 521)]
+    assert prp.shard_worktodo(lines, 0, 2) == [("prp", 136279841), ("ll", 136279901), ("ll", 127)]
+    assert prp.shard_worktodo(lines, 1, 2) == [("prp", 136279879), ("ll", 85473391), ("prp", 521)]
+
+
+def test_residue_formatting_matches_oracle():
+    p = 9941
+    o = orc.Oracle(p, 1)
+    o.set_value(0, 3**500)
+    d = o.digits(0)
+    assert np.array_equal(prp.pack_words(d, p), orc.pack_words(d, p))
+    w = prp.prp3_div9(p, prp.pack_words(d, p))
+    assert (prp.format_res64(w), prp.format_res2048(w)) == orc.prp_type1_hex(d, p)
+    assert prp.digits_equal_to(d, 3**500 % ((1 << p) - 1)) and not prp.digits_equal_to(d, 9)
+
+
+@pytest.mark.gpu
+def test_c2_9815459_partial_run_with_gerbicz_check():
+    """BASELINE config C2: PRP p=9815459 (n=2^19) with the Gerbicz-Li check on: the first 2*B+5 iterations
+    of the real schedule plus a forced check, compared with the oracle's residue."""
+    p = 9815459
+    B = int(p ** 0.5)
+    msgs = []
+    from prmers_amd import Engine
+    with Engine(p, prp.REGISTERS) as e:
+        # j % B == 0 happens every B iterations; checklevel=1 verifies at each of them
+        r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, max_iters=2 * B + 5, log=msgs.append)
+        assert r["gerbicz_errors"] == 0 and r["gerbicz_checks"] >= 2, msgs
+        o = orc.Oracle(p, 1)
+        o.set(0, 3)
+        for _ in range(r["iterations"]):
+            o.square_mul(0)
+        assert np.array_equal(e.digits(prp.R0), o.digits(0))
