@@ -114,6 +114,13 @@ def main():
         sweep_bytes = 16 * n
         achieved = sweep_bytes / (dom_ms * 1e-3) / 1e9
         ms_per_step = 1e3 * elapsed / args.steps
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile.sh)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tj.get("plan") == __import__("prmers_amd").resolve_plan(p, args.plan):
+                traffic = tj.get(dom)
+        except Exception:
+            traffic = None
         out = {
             "metric": "PRP squaring throughput at p~136M (Marin IBDWT, one exponent per GPU)",
             "value": round(world * args.steps / elapsed, 3),
@@ -133,7 +140,7 @@ def main():
                        "parallelism": "replicas: one exponent per GPU, no data-path collective"},
             "event_ms_per_step": round(ev_ms / args.steps, 5),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": sweep_bytes,
                          "kernel_ms": {k: round(v, 5) for k, v in kern.items()},
                          "iteration": {"algorithmic_bytes": 48 * n,
