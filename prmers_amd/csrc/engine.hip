@@ -70,6 +70,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   dp_.r5 = pl_.r5; dp_.C = pl_.C; dp_.q = pl_.q; dp_.t = pl_.t; dp_.twh = pl_.twh;
   dp_.I4 = pl_.I4; dp_.I4inv = pl_.I4inv;
   for (int i = 0; i < 5; ++i) { dp_.W5[i] = pl_.W5[i]; dp_.W5i[i] = pl_.W5i[i]; }
+  { const char* tn = std::getenv("MI355_TUNE"); dp_.tune = tn ? uint32_t(std::atoi(tn)) : 0u; }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
   {
     // kernel set: the register-resident radix-8 kernels where the shape is served, else the generic

@@ -12,6 +12,7 @@ struct DevPlan {
   const uint64_t *TWlo, *TWhi, *UT1, *UT2;
   uint64_t I4, I4inv;
   uint64_t W5[5], W5i[5];
+  uint32_t tune;   // experiment bits (MI355_TUNE): 1 = XCD-contiguous tile order, 2/4/8 = stagger co-resident groups
 };
 
 hipError_t configure_kernels(size_t lds_front, size_t lds_mid);

@@ -29,6 +29,17 @@ namespace mi355 {
 namespace v2 {
 
 struct alignas(16) P2 { uint64_t a, b; };
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+// streaming (non-temporal) access to the work buffer: every element is read once and written once per sweep
+__device__ __forceinline__ P2 ld_stream(const P2* p, bool nt) {
+  if (nt) { const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p)); return {v.x, v.y}; }
+  return *p;
+}
+__device__ __forceinline__ void st_stream(P2* p, P2 v, bool nt) {
+  if (nt) { u64x2 w; w.x = v.a; w.y = v.b; __builtin_nontemporal_store(w, reinterpret_cast<u64x2*>(p)); }
+  else *p = v;
+}
 
 __device__ __forceinline__ uint32_t phys(uint32_t i) { return i + (i >> 3); }
 constexpr uint32_t kLdsSlots = 4096 + 512;
@@ -68,6 +79,21 @@ __device__ __forceinline__ void digit_info(const DevPlan& pl, uint32_t sa, uint3
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_v2[];
 
+// block -> tile for the back sweep: blocks that share an XCD (b, b+8, ... under round-robin dispatch)
+// get neighbouring tiles, so the two 64-byte halves of a 128-byte work-buffer line meet in one L2
+// (speed only; measured 73 -> 66 us at C3).  MI355_TUNE bit 0 switches it off.
+__device__ __forceinline__ uint32_t tile_of_block(const DevPlan& pl, uint32_t b, uint32_t nblocks) {
+  if (!(pl.tune & 1) && (nblocks % 8 == 0)) return (b & 7) * (nblocks >> 3) + (b >> 3);
+  return b;
+}
+// experiment: delay one of two (presumed) co-resident work-groups at start.  tune bits 1-3 = sleeps of
+// ~3.4 us, bit 4: pairing rule (0: blocks b, b+256; 1: blocks b, b+8)
+__device__ __forceinline__ void stagger(const DevPlan& pl) {
+  const uint32_t reps = (pl.tune >> 1) & 7;
+  const bool second = (pl.tune & 16) ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
+  if (reps && second) for (uint32_t i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // exchange helpers: barrier, write 8, barrier, read 8
 #define EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)                      \
   __syncthreads();                                                 \
@@ -94,6 +120,7 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
                                                       uint64_t* __restrict__ Wout, int mode) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), row = blockIdx.x;
+  stagger(pl);
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 4096;
   P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * 4096;
   const uint64_t* __restrict__ UT = pl.UT2;   // omega_4096^e
@@ -101,7 +128,7 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
 
   // ---- forward ----
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = in[512 * j + t];
+  for (int j = 0; j < 8; ++j) x[j] = ld_stream(&in[512 * j + t], pl.tune & 32);
   dft8p<false>(x);
 #pragma unroll
   for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (gf::LOG2_W64 * k * wave) % 192);
@@ -190,7 +217,7 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (192 - (gf::LOG2_W64 * k * wave) % 192) % 192);
   dft8p<true>(x);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
+  for (int j = 0; j < 8; ++j) st_stream(&out[512 * j + t], x[j], pl.tune & 64);
 }
 
 // previous run (in digit order) of run (T, i1); see kernels.hip
@@ -307,7 +334,7 @@ __global__ void __launch_bounds__(512, 4) k1_cols1024x4(DevPlan pl, const uint32
 __global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
                                                         uint64_t* __restrict__ cbuf, uint32_t a) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, blockIdx.x, gridDim.x);
   P2 x[8];
   {
     const uint32_t c = t & 3, k2 = (t >> 2) & 7, k1 = (t >> 5) & 1, k3 = t >> 6;
