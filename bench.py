@@ -39,7 +39,7 @@ def seeded_digits(p, n, seed):
     return d | (width << np.uint64(32))
 
 
-def cpu_baseline(p, sample_iters=6):
+def cpu_baseline(p, sample_iters=100):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc   # the oracle is the checker / CPU baseline only (never on the product path)
     o = orc.Oracle(p, 1)
@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--exponent", type=int, default=0, help="override the exponent (testing)")
     ap.add_argument("--plan", type=str, default=None, help="plan override, e.g. m2=4096,c=4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo to rehearse")
+    ap.add_argument("--all-ranks-on-device", type=int, default=-1,
+                    help="rehearsal only: put every rank on this device (implies a gloo status reduction)")
     args = ap.parse_args()
 
     import torch
@@ -72,11 +75,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    rehearsal = args.all_ranks_on_device >= 0
+    if rehearsal:
+        local_rank, args.dist_backend = args.all_ranks_on_device, "gloo"
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     p = args.exponent or EXPONENTS[rank % len(EXPONENTS)]
     eng = Engine(p, 2, device=local_rank, plan=args.plan)
@@ -97,8 +107,8 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
 
-    status = torch.tensor([1, 0, args.steps], dtype=torch.int64, device="cuda")   # ok, gerbicz errors, iterations
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    status = torch.tensor([1, 0, args.steps], dtype=torch.int64, device=red_dev)   # ok, gerbicz errors, iterations
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(status, op=dist.ReduceOp.SUM)   # the only cross-GPU traffic: a 24-byte status word
@@ -137,7 +147,8 @@ def main():
             "config": {"workload": "square_mul x<-x^2 mod 2^p-1, p=%d, n=%d words" % (p, n),
                        "plan": __import__("prmers_amd").resolve_plan(p, args.plan),
                        "exponents": EXPONENTS[:world] if not args.exponent else [p],
-                       "parallelism": "replicas: one exponent per GPU, no data-path collective"},
+                       "parallelism": "replicas: one exponent per GPU, no data-path collective" +
+                                      (" [REHEARSAL: all ranks on one device]" if rehearsal else "")},
             "event_ms_per_step": round(ev_ms / args.steps, 5),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

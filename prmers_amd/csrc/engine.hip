@@ -48,7 +48,8 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
   const size_t total = padded(pl_.SA.size() * 4) + padded(pl_.SB.size() * 4) + padded(pl_.TA.size() * 8) * 2 +
                        padded(pl_.TB.size() * 8) * 2 + padded(pl_.TWlo.size() * 8) + padded(pl_.TWhi.size() * 8) +
-                       padded(pl_.UT1.size() * 8) + padded(pl_.UT2.size() * 8);
+                       padded(pl_.UT1.size() * 8) + padded(pl_.UT2.size() * 8) + padded(pl_.S2r.size() * 8) * 2 +
+                       padded(pl_.S1r.size() * 8) * 2 + 1024;
   HIPCHK(hipMalloc(&tables_, total));
   std::vector<unsigned char> host(total, 0);
   unsigned char* base = static_cast<unsigned char*>(tables_);
@@ -63,6 +64,10 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   dp_.TWhi = upload(cur, base, pl_.TWhi, host);
   dp_.UT1 = upload(cur, base, pl_.UT1, host);
   dp_.UT2 = upload(cur, base, pl_.UT2, host);
+  dp_.S2r = pl_.S2r.empty() ? nullptr : upload(cur, base, pl_.S2r, host);
+  dp_.S2ri = pl_.S2ri.empty() ? nullptr : upload(cur, base, pl_.S2ri, host);
+  dp_.S1r = pl_.S1r.empty() ? nullptr : upload(cur, base, pl_.S1r, host);
+  dp_.S1ri = pl_.S1ri.empty() ? nullptr : upload(cur, base, pl_.S1ri, host);
   HIPCHK(hipMemcpy(tables_, host.data(), total, hipMemcpyHostToDevice));
 
   dp_.n = uint32_t(pl_.n); dp_.m = uint32_t(pl_.m);

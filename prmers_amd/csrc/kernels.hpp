@@ -10,6 +10,7 @@ struct DevPlan {
   const uint32_t *SA, *SB;
   const uint64_t *TA, *TAi, *TB, *TBi;
   const uint64_t *TWlo, *TWhi, *UT1, *UT2;
+  const uint64_t *S2r, *S2ri, *S1r, *S1ri;   // seam tables of the radix-8 kernels (null when the shape is not served)
   uint64_t I4, I4inv;
   uint64_t W5[5], W5i[5];
   uint32_t tune;   // experiment bits (MI355_TUNE): 1 = XCD-contiguous tile order, 2/4/8 = stagger co-resident groups

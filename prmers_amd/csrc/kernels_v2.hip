@@ -123,7 +123,6 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   stagger(pl);
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 4096;
   P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * 4096;
-  const uint64_t* __restrict__ UT = pl.UT2;   // omega_4096^e
   P2 x[8];
 
   // ---- forward ----
@@ -136,11 +135,9 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   dft8p<false>(x);
   {
     const uint32_t k1 = t & 7, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S2r + b * 64 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const uint32_t e = (k1 + 8 * k2) * b;
-      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], UT[e]);
-    }
+    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[8 * k2]);
   }
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false>(x);
@@ -205,11 +202,9 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
   {
     const uint32_t k1 = t & 7, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S2ri + b * 64 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const uint32_t e = (k1 + 8 * k2) * b;
-      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], UT[(4096 - e) & 4095]);
-    }
+    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[8 * k2]);
   }
   dft8p<true>(x);
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
@@ -289,11 +284,9 @@ __global__ void __launch_bounds__(512, 4) k1_cols1024x4(DevPlan pl, const uint32
   dft8p<false>(x);
   {
     const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S1r + b * 16 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const uint32_t e = (k1 + 2 * k2) * b;   // < 16 * 64
-      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], pl.UT1[e]);
-    }
+    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[2 * k2]);
   }
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false>(x);
@@ -373,11 +366,9 @@ __global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
   {
     const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S1ri + b * 16 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) {
-      const uint32_t e = (k1 + 2 * k2) * b;
-      if (k2 != 0 || k1 != 0) x[k2] = p2_mul(x[k2], pl.UT1[(1024 - e) & 1023]);
-    }
+    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[2 * k2]);
   }
   dft8p<true>(x);
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)

@@ -62,6 +62,9 @@ struct Plan {
   std::vector<uint64_t> TA, TAi, TB, TBi;  // 2^(1/n) powers; TAi carries the 1/m factor
   std::vector<uint64_t> TWlo, TWhi;      // two-level omega_m table
   std::vector<uint64_t> UT1, UT2;        // omega_M1^e (e < M1), omega_M2^e (e < M2)
+  // seam twiddles of the radix-8 kernels, laid out [b][ka] so that a wave reads runs of consecutive entries:
+  // S2r[b*64+ka] = omega_4096^(ka*b) (rows of 4096 = 64 x 64), S1r[b*16+ka] = omega_1024^(ka*b) (columns 16 x 64); *i = inverses
+  std::vector<uint64_t> S2r, S2ri, S1r, S1ri;
   uint64_t I4 = 0, I4inv = 0;            // omega_4, omega_4^-1 (forward root convention)
   uint64_t W5[5] = {1, 0, 0, 0, 0}, W5i[5] = {1, 0, 0, 0, 0};
 
@@ -182,6 +185,20 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   const uint64_t om1 = gf::pow(om, pl.M2), om2 = gf::pow(om, pl.M1);
   pl.UT1.resize(pl.M1); pl.UT1[0] = 1; for (uint32_t i = 1; i < pl.M1; ++i) pl.UT1[i] = gf::mul(pl.UT1[i - 1], om1);
   pl.UT2.resize(pl.M2); pl.UT2[0] = 1; for (uint32_t i = 1; i < pl.M2; ++i) pl.UT2[i] = gf::mul(pl.UT2[i - 1], om2);
+  if (pl.M2 == 4096) {
+    pl.S2r.resize(4096); pl.S2ri.resize(4096);
+    for (uint32_t b = 0; b < 64; ++b) for (uint32_t ka = 0; ka < 64; ++ka) {
+      const uint32_t e = ka * b;
+      pl.S2r[b * 64 + ka] = pl.UT2[e]; pl.S2ri[b * 64 + ka] = pl.UT2[(4096 - e) & 4095];
+    }
+  }
+  if (pl.M1 == 1024) {
+    pl.S1r.resize(1024); pl.S1ri.resize(1024);
+    for (uint32_t b = 0; b < 64; ++b) for (uint32_t ka = 0; ka < 16; ++ka) {
+      const uint32_t e = ka * b;
+      pl.S1r[b * 16 + ka] = pl.UT1[e]; pl.S1ri[b * 16 + ka] = pl.UT1[(1024 - e) & 1023];
+    }
+  }
   if (m % 4 == 0) { pl.I4 = gf::pow(om, m / 4); pl.I4inv = gf::inv(pl.I4); }
   else { pl.I4 = gf::root_of_unity(4); pl.I4inv = gf::inv(pl.I4); }
   if (pl.r5 == 5) {
