@@ -278,3 +278,26 @@ def test_full_size_properties_no_oracle():
         e.copy(4, 1); e.square_mul(4); e.sub_reg(2, 4)
         e.copy(4, 0); e.mul(4, 3, 2)
         assert e.is_equal(2, 4)
+
+
+def test_c4_205271257_full_size_radix5():
+    """BASELINE config C4 (n = 5*2^21, radix-5 first stage, rows of 4096): squarings with a factor, the
+    Gerbicz-style mul and the LL subtraction vs the oracle's digit vectors."""
+    p = 205271257
+    o = orc.Oracle(p, 3)
+    assert o.n == 5 << 21
+    rng = np.random.default_rng(7)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 4) as e:
+        assert e.n == o.n
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        for a in (1, 3):
+            e.square_mul(0, a); o.square_mul(0, a)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.copy(1, 0); o.copy(1, 0)
+        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)
+        e.sub(0, 2); o.sub(0, 2)
+        e.mul(0, 2); o.mul(0, 2)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert e.res64(0) == o.res64(0)
