@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -56,18 +57,25 @@ class Engine {
   size_t algorithmic_bytes() const { return 48 * pl_.n; }
 
  private:
-  enum Kind : uint8_t { kDigits = 0, kImage = 1 };
+  // kDigits: unweighted u32 digits (+ deferred run carries / subtraction); kImage: multiplicand;
+  // kFront: front-transformed residue (work-buffer layout) left by the fused back+front sweep
+  enum Kind : uint8_t { kDigits = 0, kImage = 1, kFront = 2 };
   void check_reg(size_t r) const;
   void need_digits(size_t r, const char* op) const;
-  uint32_t* digits(size_t r) { return reinterpret_cast<uint32_t*>(regs_ + r * reg_bytes_); }
-  uint64_t* image(size_t r) { return reinterpret_cast<uint64_t*>(regs_ + r * reg_bytes_); }
+  uint32_t* digits(size_t r) { return reinterpret_cast<uint32_t*>(slot_[r]); }
+  uint64_t* image(size_t r) { return reinterpret_cast<uint64_t*>(slot_[r]); }
+  uint64_t* work() { return reinterpret_cast<uint64_t*>(slot_[nregs_]); }
+  void swap_with_work(size_t r) { std::swap(slot_[r], slot_[nregs_]); }
+  void ensure_front(size_t r);       // kDigits -> kFront (fused mode)
+  void materialize(size_t r);        // kFront -> kDigits
+  void check_device_error();
   void read_values(size_t src, std::vector<uint64_t>& v);   // natural order, strongly carried digits
   void write_values(size_t dst, const std::vector<uint32_t>& natural);
   void square_chain(size_t r, uint32_t a, hipEvent_t* ev);
   uint64_t* cbuf(size_t r) { return cbuf_ + r * pl_.runs(); }
   void normalize(size_t r);          // apply deferred run carries / small subtraction
   void run_front(size_t r);          // digits(r) -> work_, consuming pending state when the kernel can
-  void run_middle(const uint64_t* in, const uint64_t* y, uint64_t* out, int mode);
+  void run_middle(const uint64_t* in, const uint64_t* y, uint64_t* out, int mode, uint32_t sub);
   void run_back(size_t r, uint32_t a);
 
   Plan pl_;
@@ -76,8 +84,12 @@ class Engine {
   bool verbose_ = false;
   hipStream_t stream_ = nullptr;
   size_t nregs_ = 0, reg_bytes_ = 0;
-  unsigned char* regs_ = nullptr;
-  uint64_t* work_ = nullptr;
+  unsigned char* regs_ = nullptr;            // (reg_count + 1) slots of 8n bytes; the extra one is the work buffer
+  std::vector<unsigned char*> slot_;          // slot_[r]: storage of register r; slot_[reg_count]: work buffer (swappable)
+  uint64_t* cw_ = nullptr;                    // fused sweep: carry words between work-groups
+  uint32_t* flags_ = nullptr;                 // fused sweep: per-work-group epoch flags (+ error word at the end)
+  uint32_t epoch_ = 0;
+  bool fused_ = false;
   uint64_t* cbuf_ = nullptr;
   void* tables_ = nullptr;
   std::vector<uint8_t> kind_;

@@ -189,13 +189,16 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
 // middle: one work-group per row.  mode 0: square, 1: multiply by image Y, 2: forward only.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
-                                                uint64_t* __restrict__ Wout, int mode) {
+                                                uint64_t* __restrict__ Wout, int mode, uint32_t sub) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, row = blockIdx.x, M2 = pl.M2;
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * M2;
   P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * M2;
 
   for (uint32_t e = tid; e < M2; e += nthr) X[e] = in[e];
+  __syncthreads();
+  // deferred small subtraction on a front image (digit 0 -> column 0, plane a of every row, weight 1)
+  if (sub != 0 && tid == 0) X[0].a = gf::sub(X[0].a, uint64_t(sub));
   __syncthreads();
   lds_pow2_dft<false>(X, M2, pl.logM2, 1, 1, pl.UT2, M2, 1, pl.I4, tid, nthr);
   if (mode == 2) {
@@ -374,8 +377,8 @@ hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, uint64_t* W, 
   hipLaunchKernelGGL(k_front, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, digits, W);
   return hipGetLastError();
 }
-hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(k_middle, dim3(pl.M1), dim3(block_for(pl.M2 / 4 ? pl.M2 / 4 : 1)), size_t(pl.M2) * 16, s, pl, Win, Y, Wout, mode);
+hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
+  hipLaunchKernelGGL(k_middle, dim3(pl.M1), dim3(block_for(pl.M2 / 4 ? pl.M2 / 4 : 1)), size_t(pl.M2) * 16, s, pl, Win, Y, Wout, mode, sub);
   return hipGetLastError();
 }
 hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s) {

@@ -18,7 +18,7 @@ struct DevPlan {
 
 hipError_t configure_kernels(size_t lds_front, size_t lds_mid);
 hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, uint64_t* W, hipStream_t s);
-hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s);
+hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
 hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t* cbuf, hipStream_t s);
 hipError_t launch_addsub(const DevPlan& pl, uint32_t* dst, const uint32_t* src, uint64_t* cbuf, int negate, hipStream_t s);
@@ -29,8 +29,10 @@ hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hip
 bool v2_rows_supported(const DevPlan& pl);
 bool v2_cols_supported(const DevPlan& pl);
 hipError_t v2_configure();
-hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s);
+hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
-hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
+hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s);
+// fused back + front sweep, in place on a work buffer / front image (cw: [M2/8][1024] carry words, flags: [M2/8])
+hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s);
 
 }  // namespace mi355

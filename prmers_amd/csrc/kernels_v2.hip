@@ -117,7 +117,7 @@ __device__ __forceinline__ void stagger(const DevPlan& pl) {
 // mode 0: square, 1: multiply by image Y, 2: forward only (writes the image).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
-                                                      uint64_t* __restrict__ Wout, int mode) {
+                                                      uint64_t* __restrict__ Wout, int mode, uint32_t sub) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), row = blockIdx.x;
   stagger(pl);
@@ -128,6 +128,9 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   // ---- forward ----
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = ld_stream(&in[512 * j + t], pl.tune & 32);
+  // deferred small subtraction (LL's -2) on a front image: digit 0 has weight 1 and reaches column 0,
+  // plane a of every row unchanged
+  if (sub != 0 && t == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));
   dft8p<false>(x);
 #pragma unroll
   for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (gf::LOG2_W64 * k * wave) % 192);
@@ -223,48 +226,49 @@ __device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// front, M1 = 1024 = 2.8.8.8, C = 4.  Tile element (i1, c), i1 = 512 d1 + 64 d2 + 8 d3 + d4.
+// Column tiles, M1 = 1024 = 2.8.8.8, C = 4.  Tile element (i1, c), i1 = 512 d1 + 64 d2 + 8 d3 + d4.
+// front_tile (digits -> work buffer):
 //   S1 thread (d2|d3|d4) regs (d1,c): two whole runs of 8 digits -> weight -> DFT2 -> k1 ; shift omega_16^(k1 d2)
 //   S2 thread (d3|d4|k1|c) regs d2 -> k2 ; general omega_1024^((k1+2k2)(8d3+d4))
 //   S3 thread (d4|k1|c|k2) regs d3 -> k3 ; shift omega_64^(k3 d4)
 //   S4 thread (k3|k1|k2|c) regs d4 -> k4 ; k1col = k1 + 2 k2 + 16 k3 + 128 k4
 //   then the four-step twiddle omega_m^(i2 k1col) * TB (geometric in k4: one chain multiply per element)
 //   and the store to work-buffer row bitrev10(k1col), column i2 = 4T + c.
-// cbuf_in (nullable): pending run carries of this register (deferred k_carry_fix); sub: pending
-// small subtraction at digit 0 (LL's x^2 - 2), applied in the field.
+// back_tile is the mirror image, followed by unweight and the sequential carry of the thread's two runs.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512, 4) k1_cols1024x4(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
-                                                        uint32_t sub, uint64_t* __restrict__ Wout) {
-  P2* X = reinterpret_cast<P2*>(smem_v2);
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
-  P2 x[8];
 
+// weak carry of a run's incoming carry word into its first digits (adc4, marin.cl:203-212)
+__device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t T, uint32_t i1, uint64_t cin, uint32_t (&d)[8]) {
+  const uint32_t sa = pl.SA[i1];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint32_t width; bool wr;
+    digit_info(pl, sa, pl.SB[8 * T + k], width, wr);
+    const uint64_t v = uint64_t(d[k]) + cin;
+    d[k] = uint32_t(v & ((uint64_t(1) << width) - 1));
+    cin = v >> width;
+  }
+  d[3] += uint32_t(cin);
+}
+
+// digits of the thread's two runs (i1 = t and 512 + t) of tile T  ->  work buffer (forward columns).
+// sub: small constant to subtract at digit 0 of the whole number, in the field (LL's x^2 - 2).
+__device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T, uint32_t t, uint32_t lane, uint32_t wave,
+                                           const uint32_t (&dg)[2][8], uint32_t sub, uint64_t* __restrict__ Wout) {
+  P2 x[8];
 #pragma unroll
   for (int d1 = 0; d1 < 2; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
-    const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * 1024 + i1) * 2;
-    const uint4 q0 = src[0], q1 = src[1];
-    uint32_t d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     const uint32_t sa = pl.SA[i1];
     const uint64_t ta = pl.TA[i1];
-    uint32_t width[8]; bool wrap[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) digit_info(pl, sa, pl.SB[8 * T + k], width[k], wrap[k]);
-    if (cbuf_in) {   // weak carry of the previous run's carry word (adc4, marin.cl:203-212)
-      uint64_t cin = carry_in_of(pl, cbuf_in, T, i1);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const uint64_t v = uint64_t(d[k]) + cin;
-        d[k] = uint32_t(v & ((uint64_t(1) << width[k]) - 1));
-        cin = v >> width[k];
-      }
-      d[3] += uint32_t(cin);
-    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      uint64_t a0 = gf::mul_u32(ta, d[2 * c]), a1 = gf::mul_u32(ta, d[2 * c + 1]);
-      if (wrap[2 * c]) a0 = gf::half(a0);
-      if (wrap[2 * c + 1]) a1 = gf::half(a1);
+      uint32_t w0, w1; bool wr0, wr1;
+      digit_info(pl, sa, pl.SB[8 * T + 2 * c], w0, wr0);
+      digit_info(pl, sa, pl.SB[8 * T + 2 * c + 1], w1, wr1);
+      uint64_t a0 = gf::mul_u32(ta, dg[d1][2 * c]), a1 = gf::mul_u32(ta, dg[d1][2 * c + 1]);
+      if (wr0) a0 = gf::half(a0);
+      if (wr1) a1 = gf::half(a1);
       x[4 * d1 + c] = {a0, a1};
     }
     if (sub != 0 && T == 0 && i1 == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));   // digit 0 has weight 1
@@ -321,21 +325,21 @@ __global__ void __launch_bounds__(512, 4) k1_cols1024x4(DevPlan pl, const uint32
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// back: mirror of front, then unweight and carry each of the thread's two runs sequentially.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
-                                                        uint64_t* __restrict__ cbuf, uint32_t a) {
-  P2* X = reinterpret_cast<P2*>(smem_v2);
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, blockIdx.x, gridDim.x);
+// work buffer -> digits of the thread's two runs of tile T (inverse columns, unweight, x a, carry).
+// scale: extra field factor (1, or M2 when the input is a front image rather than a middle output).
+// carry0[d1]: carry entering run d1 (strong: propagated through the whole run); cout[d1]: carry leaving it.
+__device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, uint32_t t, uint32_t lane, uint32_t wave,
+                                          const uint64_t* __restrict__ Win, uint32_t a, uint64_t scale,
+                                          const uint64_t (&carry0)[2], uint32_t (&dg)[2][8], uint64_t (&cout)[2]) {
   P2 x[8];
   {
     const uint32_t c = t & 3, k2 = (t >> 2) & 7, k1 = (t >> 5) & 1, k3 = t >> 6;
     const uint32_t kb = k1 + 2 * k2 + 16 * k3;
     const uint32_t i2 = 4 * T + c;
     const uint64_t ea = (uint64_t(i2) * kb) % pl.m, eb = (uint64_t(i2) * 128) % pl.m;
-    const uint64_t A = tw_lookup(pl, ea ? pl.m - ea : 0);
+    uint64_t A = tw_lookup(pl, ea ? pl.m - ea : 0);
     const uint64_t B = tw_lookup(pl, eb ? pl.m - eb : 0);
+    if (scale != 1) A = gf::mul(A, scale);
     uint64_t ca = gf::mul(A, pl.TBi[2 * i2]), cb = gf::mul(A, pl.TBi[2 * i2 + 1]);
     const uint32_t row0 = __brev(kb) >> 22;
     const P2* W = reinterpret_cast<const P2*>(Win);
@@ -383,14 +387,12 @@ __global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64
     x[c] = {gf::add(u.a, v.a), gf::add(u.b, v.b)};
     x[4 + c] = {gf::sub(u.a, v.a), gf::sub(u.b, v.b)};
   }
-
 #pragma unroll
   for (int d1 = 0; d1 < 2; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
     const uint32_t sa = pl.SA[i1];
     const uint64_t tai = pl.TAi[i1];
-    uint64_t carry = 0;
-    uint32_t o[8];
+    uint64_t carry = carry0[d1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       uint32_t width; bool wrap;
@@ -401,13 +403,114 @@ __global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
       const uint64_t dlo = u & mask, chi = u >> width;
       const uint64_t r = dlo * a + carry;
-      o[k] = uint32_t(r & mask);
+      dg[d1][k] = uint32_t(r & mask);
       carry = (r >> width) + chi * a;
     }
+    cout[d1] = carry;
+  }
+}
+
+// front sweep: digits (+ deferred run carries cbuf_in, nullable; + deferred subtraction) -> work buffer
+__global__ void __launch_bounds__(512, 4) k1_cols1024x4(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
+                                                        uint32_t sub, uint64_t* __restrict__ Wout) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
+  uint32_t dg[2][8];
+#pragma unroll
+  for (int d1 = 0; d1 < 2; ++d1) {
+    const uint32_t i1 = 512 * d1 + t;
+    const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * 1024 + i1) * 2;
+    const uint4 q0 = src[0], q1 = src[1];
+    dg[d1][0] = q0.x; dg[d1][1] = q0.y; dg[d1][2] = q0.z; dg[d1][3] = q0.w;
+    dg[d1][4] = q1.x; dg[d1][5] = q1.y; dg[d1][6] = q1.z; dg[d1][7] = q1.w;
+    if (cbuf_in) apply_carry_in(pl, T, i1, carry_in_of(pl, cbuf_in, T, i1), dg[d1]);
+  }
+  front_tile(pl, X, T, t, lane, wave, dg, sub, Wout);
+}
+
+// back sweep: work buffer -> digits + one carry word per run
+__global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+                                                        uint64_t* __restrict__ cbuf, uint32_t a, uint64_t scale) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, blockIdx.x, gridDim.x);
+  uint32_t dg[2][8];
+  uint64_t cout[2];
+  const uint64_t zero[2] = {0, 0};
+  back_tile(pl, X, T, t, lane, wave, Win, a, scale, zero, dg, cout);
+#pragma unroll
+  for (int d1 = 0; d1 < 2; ++d1) {
+    const uint32_t i1 = 512 * d1 + t;
     uint4* dst = reinterpret_cast<uint4*>(digits) + (size_t(T) * 1024 + i1) * 2;
-    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    cbuf[size_t(T) * 1024 + i1] = carry;
+    dst[0] = make_uint4(dg[d1][0], dg[d1][1], dg[d1][2], dg[d1][3]);
+    dst[1] = make_uint4(dg[d1][4], dg[d1][5], dg[d1][6], dg[d1][7]);
+    cbuf[size_t(T) * 1024 + i1] = cout[d1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused back + front sweep (work buffer -> work buffer, in place): the residue never goes to memory
+// as digits between two squarings.  A work-group owns the neighbouring tiles A = 2b and B = 2b+1:
+//   back(A) [carry-in 0]  ->  back(B) [carry-in = A's carry-out, same runs, same threads]
+//   -> publish B's carry-out words (write-through stores, then one flag store per work-group)
+//   -> front(B)  ->  wait for the previous work-group's flag, fetch its carry words -> front(A).
+// Only A's carry-in crosses work-groups, and it is needed last, so the wait is normally over before it
+// starts.  No work-group waits before it has published, so the chain cannot deadlock under in-order
+// dispatch; the poll is bounded anyway and reports through *err.  Hand-off protocol:
+// cdna_hip_programming.md Guideline 16, "sc1 stores + drained flag" row (flag = epoch of this launch).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* __restrict__ Wbuf, uint64_t* __restrict__ cw,
+                                                         uint32_t* __restrict__ flags, uint32_t epoch, uint32_t a, uint32_t* __restrict__ err) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t b = blockIdx.x, G = gridDim.x;
+  uint32_t dnew[2][8], dhold[2][8];
+  uint64_t co[2] = {0, 0};
+#pragma unroll 1
+  for (uint32_t s = 0; s < 3; ++s) {
+    const uint32_t T = (s == 1) ? 2 * b + 1 : 2 * b;
+    if (s < 2) {
+      uint64_t cout[2];
+      back_tile(pl, X, T, t, lane, wave, Wbuf, a, 1, co, dnew, cout);
+      co[0] = cout[0]; co[1] = cout[1];
+    }
+    if (s == 0) {
+#pragma unroll
+      for (int d1 = 0; d1 < 2; ++d1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dhold[d1][k] = dnew[d1][k];
+      continue;
+    }
+    if (s == 1) {
+      // publish the carry words leaving tile B (they enter the next work-group's tile A)
+#pragma unroll
+      for (int d1 = 0; d1 < 2; ++d1)
+        __hip_atomic_store(cw + size_t(b) * 1024 + 512 * d1 + t, co[d1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // tile A's runs continue the previous work-group's tile B (work-group 0: the last one, one row up)
+      const uint32_t pb = b ? b - 1 : G - 1;
+      if (t == 0) {
+        uint32_t ok = 0;
+        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+          if (__hip_atomic_load(flags + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = 1; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) atomicOr(err, 1u);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int d1 = 0; d1 < 2; ++d1) {
+        const uint32_t i1 = 512 * d1 + t;
+        const uint32_t pi = b ? i1 : (i1 ? i1 - 1 : 1023);
+        const uint64_t cin = __hip_atomic_load(cw + size_t(pb) * 1024 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dnew[d1][k] = dhold[d1][k];
+        apply_carry_in(pl, T, i1, cin, dnew[d1]);
+      }
+    }
+    front_tile(pl, X, T, t, lane, wave, dnew, 0, Wbuf);
   }
 }
 
@@ -416,25 +519,31 @@ __global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64
 // ------------------------------- launch wrappers ---------------------------------------------
 
 bool v2_rows_supported(const DevPlan& pl) { return pl.M2 == 4096; }
-bool v2_cols_supported(const DevPlan& pl) { return pl.M1 == 1024 && pl.r5 == 1 && pl.C == 4; }
+bool v2_cols_supported(const DevPlan& pl) { return pl.M1 == 1024 && pl.r5 == 1 && pl.C == 4 && pl.M2 >= 8; }
 
 hipError_t v2_configure() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k1_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k3_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k3_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k31_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes + 64));
 }
-hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(v2::k2_rows4096, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, mode);
+hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
+  hipLaunchKernelGGL(v2::k2_rows4096, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, mode, sub);
   return hipGetLastError();
 }
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
   hipLaunchKernelGGL(v2::k1_cols1024x4, dim3(pl.M2 / 4), dim3(512), v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
   return hipGetLastError();
 }
-hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s) {
-  hipLaunchKernelGGL(v2::k3_cols1024x4, dim3(pl.M2 / 4), dim3(512), v2::kLdsBytes, s, pl, W, digits, cbuf, a);
+hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s) {
+  hipLaunchKernelGGL(v2::k3_cols1024x4, dim3(pl.M2 / 4), dim3(512), v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale);
+  return hipGetLastError();
+}
+hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s) {
+  hipLaunchKernelGGL(v2::k31_cols1024x4, dim3(pl.M2 / 8), dim3(512), v2::kLdsBytes + 64, s, pl, W, cw, flags, epoch, a, err);
   return hipGetLastError();
 }
 

@@ -301,3 +301,30 @@ def test_c4_205271257_full_size_radix5():
         e.mul(0, 2); o.mul(0, 2)
         assert np.array_equal(e.digits(0), o.digits(0))
         assert e.res64(0) == o.res64(0)
+
+
+@pytest.mark.parametrize("p,plan", [(300007, "m2=8,c=4"), (136279841, None)])
+def test_fused_back_front_sweep(p, plan, monkeypatch):
+    """MI355_FUSED=1: the residue stays a front image between squarings (inter-work-group carry hand-off);
+    every engine operation must still agree with the oracle."""
+    monkeypatch.setenv("MI355_FUSED", "1")
+    o = orc.Oracle(p, 4)
+    rng = np.random.default_rng(p)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 5, plan=plan) as e:
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        for a in (1, 1, 3):
+            e.square_mul(0, a); o.square_mul(0, a)
+        assert np.array_equal(e.digits(0), o.digits(0))           # front image -> digits
+        for _ in range(3):                                         # LL steps: the subtraction rides on the front image
+            e.square_mul(0); e.sub(0, 2); o.square_mul(0); o.sub(0, 2)
+        e.copy(1, 0); o.copy(1, 0)                                 # copy of a front image with a pending subtraction
+        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)         # multiplicand straight from the front image
+        e.square_mul(0); o.square_mul(0)
+        e.mul(0, 2, 5); o.mul(0, 2, 5)
+        e.add(0, 1); o.add(0, 1)
+        e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert np.array_equal(e.digits(1), o.digits(1))
+        e.sync()

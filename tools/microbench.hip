@@ -89,7 +89,8 @@ int main() {
 
   // ---- ALU ----
   {
-    const int blocks = 256 * 8, threads = 256, iters = 2000;
+    const int blocks = getenv("MB_BLOCKS") ? atoi(getenv("MB_BLOCKS")) : 256 * 8, threads = 256, iters = 2000;
+    printf("ALU section: blocks=%d (%.1f waves/SIMD)\n", blocks, blocks * 4.0 / 1024.0);
     uint64_t* out; CK(hipMalloc(&out, (size_t)blocks * threads * 8));
     const char* names[] = {"gf::mul", "gf::add+sub", "mul_pow2(24)", "mul_pow2(48)", "mul_pow2(72)", "mad_u64_u32", "mul_lo+mul_hi", "gf::sqr", "gf::mul_u32"};
     for (int mode = 0; mode < 9; ++mode) {
@@ -117,6 +118,7 @@ int main() {
     CK(hipFree(out));
   }
 
+  if (getenv("MB_ALU_ONLY")) return 0;
   // ---- copy ----
   for (size_t mib : {64, 1024}) {
     size_t bytes = mib << 20, n16 = bytes / 16;
