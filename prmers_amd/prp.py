@@ -255,3 +255,21 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     return {"exponent": p, "mode": mode, "is_prime": bool(is_prime) and it >= total, "res64": format_res64(words),
             "res2048": format_res2048(words), "iterations": it, "gerbicz_checks": checks,
             "gerbicz_errors": errors, "complete": it >= total}
+
+
+def result_json(r, fft_length, program_version="mi355-marin-hip 0.1", port=8, user="", computer="", aid="", timestamp=""):
+    """Result line in the reference's PrimeNet-style JSON (src/io/JsonBuilder.cpp:322-472): same keys, same
+    order for the PRP / LL work types ("status" P/C, "worktype" PRP-3 / LL, res64, res2048 + residue-type 1
+    for PRP, errors.gerbicz, shift-count 0, fft-length, program)."""
+    import json
+    prp_mode = r["mode"] == "prp"
+    out = [("status", "P" if r["is_prime"] else "C"), ("exponent", r["exponent"]), ("worktype", "PRP-3" if prp_mode else "LL"),
+           ("res64", r["res64"])]
+    if prp_mode:
+        out += [("res2048", r["res2048"]), ("residue-type", 1)]
+    out += [("errors", {"gerbicz": r["gerbicz_errors"]}), ("shift-count", 0), ("fft-length", int(fft_length)),
+            ("program", {"name": "prmers", "version": program_version, "port": port})]
+    for k, v in (("user", user), ("computer", computer), ("aid", aid), ("timestamp", timestamp)):
+        if v:
+            out.append((k, v))
+    return json.dumps(dict(out), separators=(",", ":"))

@@ -131,3 +131,18 @@ def test_c2_9815459_partial_run_with_gerbicz_check():
         for _ in range(r["iterations"]):
             o.square_mul(0)
         assert np.array_equal(e.digits(prp.R0), o.digits(0))
+
+
+def test_result_json_shape():
+    """keys and order of the reference's PRP / LL result JSON (src/io/JsonBuilder.cpp:396-441)."""
+    with orc.OracleEngine(127, prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, 127, "prp")
+        js = prp.result_json(r, e.get_size())
+    assert js.startswith('{"status":"P","exponent":127,"worktype":"PRP-3","res64":"0000000000000001","res2048":"')
+    d = json.loads(js)
+    assert list(d)[:9] == ["status", "exponent", "worktype", "res64", "res2048", "residue-type", "errors", "shift-count", "fft-length"]
+    assert d["errors"] == {"gerbicz": 0} and d["fft-length"] == 8 and d["residue-type"] == 1
+    with orc.OracleEngine(1001, prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, 1001, "ll")
+        d = json.loads(prp.result_json(r, e.get_size()))
+    assert d["status"] == "C" and d["worktype"] == "LL" and "res2048" not in d
