@@ -13,7 +13,7 @@ struct DevPlan {
   const uint64_t *S2r, *S2ri, *S1r, *S1ri;   // seam tables of the radix-8 kernels (null when the shape is not served)
   uint64_t I4, I4inv;
   uint64_t W5[5], W5i[5];
-  uint32_t tune;   // experiment bits (MI355_TUNE): 1 = XCD-contiguous tile order, 2/4/8 = stagger co-resident groups
+  uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs
 };
 
 hipError_t configure_kernels(size_t lds_front, size_t lds_mid);

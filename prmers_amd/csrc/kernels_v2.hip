@@ -29,17 +29,6 @@ namespace mi355 {
 namespace v2 {
 
 struct alignas(16) P2 { uint64_t a, b; };
-typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-
-// streaming (non-temporal) access to the work buffer: every element is read once and written once per sweep
-__device__ __forceinline__ P2 ld_stream(const P2* p, bool nt) {
-  if (nt) { const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p)); return {v.x, v.y}; }
-  return *p;
-}
-__device__ __forceinline__ void st_stream(P2* p, P2 v, bool nt) {
-  if (nt) { u64x2 w; w.x = v.a; w.y = v.b; __builtin_nontemporal_store(w, reinterpret_cast<u64x2*>(p)); }
-  else *p = v;
-}
 
 __device__ __forceinline__ uint32_t phys(uint32_t i) { return i + (i >> 3); }
 constexpr uint32_t kLdsSlots = 4096 + 512;
@@ -86,14 +75,6 @@ __device__ __forceinline__ uint32_t tile_of_block(const DevPlan& pl, uint32_t b,
   if (!(pl.tune & 1) && (nblocks % 8 == 0)) return (b & 7) * (nblocks >> 3) + (b >> 3);
   return b;
 }
-// experiment: delay one of two (presumed) co-resident work-groups at start.  tune bits 1-3 = sleeps of
-// ~3.4 us, bit 4: pairing rule (0: blocks b, b+256; 1: blocks b, b+8)
-__device__ __forceinline__ void stagger(const DevPlan& pl) {
-  const uint32_t reps = (pl.tune >> 1) & 7;
-  const bool second = (pl.tune & 16) ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
-  if (reps && second) for (uint32_t i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
-}
-
 // exchange helpers: barrier, write 8, barrier, read 8
 #define EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)                      \
   __syncthreads();                                                 \
@@ -120,14 +101,13 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
                                                       uint64_t* __restrict__ Wout, int mode, uint32_t sub) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), row = blockIdx.x;
-  stagger(pl);
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 4096;
   P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * 4096;
   P2 x[8];
 
   // ---- forward ----
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = ld_stream(&in[512 * j + t], pl.tune & 32);
+  for (int j = 0; j < 8; ++j) x[j] = in[512 * j + t];
   // deferred small subtraction (LL's -2) on a front image: digit 0 has weight 1 and reaches column 0,
   // plane a of every row unchanged
   if (sub != 0 && t == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));
@@ -215,7 +195,7 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (192 - (gf::LOG2_W64 * k * wave) % 192) % 192);
   dft8p<true>(x);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) st_stream(&out[512 * j + t], x[j], pl.tune & 64);
+  for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
 }
 
 // previous run (in digit order) of run (T, i1); see kernels.hip

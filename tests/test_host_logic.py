@@ -90,3 +90,40 @@ def test_cpp_adapter_reg_contract_on_gpu():
         exe = _build_adapter(td)
         out = subprocess.run([exe, "run", E.LIB_PATH], capture_output=True, text=True)
         assert out.returncode == 0 and "passed" in out.stdout, out.stdout + out.stderr
+
+
+def _build_cli(td):
+    exe = os.path.join(td, "mi355_prp")
+    gmp = "/usr/lib/x86_64-linux-gnu/libgmp.so.10"
+    inc = [i for i in ("/opt/conda/include", "/usr/include") if os.path.exists(os.path.join(i, "gmp.h"))]
+    if not inc or not os.path.exists(gmp):
+        pytest.skip("gmp headers/library not available")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + inc[0], "-o", exe,
+                           os.path.join(ROOT, "examples", "prp_cli.cpp"), "-ldl", gmp])
+    return exe
+
+
+def test_cpp_driver_fails_loudly_without_gpu():
+    from prmers_amd import engine as E
+    import torch
+    if torch.cuda.is_available() or not os.path.exists(E.LIB_PATH):
+        pytest.skip("needs the built library and no GPU")
+    with tempfile.TemporaryDirectory() as td:
+        out = subprocess.run([_build_cli(td), "127", "-lib", E.LIB_PATH], capture_output=True, text=True)
+        assert out.returncode == 2 and "no CPU fallback" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_driver_prp_ll_and_fault_injection_on_gpu():
+    """examples/prp_cli.cpp (engine_hip + the reference's driver loop in C++): M9941 with -erroriter reproduces the
+    golden messages of unit_tests.sh:24-50; LL and composite cases."""
+    from prmers_amd import engine as E
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_cli(td)
+        run = lambda *a: subprocess.run([exe, *a, "-lib", E.LIB_PATH], capture_output=True, text=True)   # noqa: E731
+        o = run("9941", "-erroriter", "55")
+        assert o.returncode == 0, o.stderr
+        assert "Injected error at iteration 55" in o.stdout and "[Gerbicz Li] Check FAILED! iter=9941" in o.stdout
+        assert "[Gerbicz Li] Restore iter=0 (j=9940)" in o.stdout and "probably prime" in o.stdout
+        assert "probably prime" in run("607", "-ll").stdout
+        assert "composite" in run("1001").stdout
