@@ -38,10 +38,10 @@ int main(int argc, char** argv) {
     uint64_t level = checklevel ? checklevel : uint64_t(600000.0 / double(B));
     if (level == 0) level = 1;
     uint64_t itersave = 0, jsave = total - 1, checkpass = 0, errors = 0, done = 0;
-    bool errordone = false;
+    bool errordone = false, complete = true;
     mpz_t z0, z1; mpz_inits(z0, z1, nullptr);
     for (uint64_t iter = 0, j = total - 1; iter < total; ++iter, --j) {
-      if (maxiters && done >= maxiters) break;
+      if (maxiters && done >= maxiters) { complete = false; break; }
       eng->square_mul(R0);
       if (ll) eng->sub(R0, 2);
       ++done;
@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     engine::digit d(eng.get(), R0);
     const bool prime = ll ? (d.equal_to(0) || d.equal_to_Mp()) : d.equal_to(9);
     std::printf("M%u %s: %s  res64(raw)=%016llX  gerbicz_errors=%llu  n=%zu\n", p, ll ? "LL" : "PRP-3",
-                (done == total) ? (prime ? "probably prime" : "composite") : "partial run",
+                complete ? (prime ? "probably prime" : "composite") : "partial run",
                 (unsigned long long)d.res64(), (unsigned long long)errors, eng->get_size());
     return 0;
   } catch (const std::exception& e) {
