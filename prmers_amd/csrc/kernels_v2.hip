@@ -47,10 +47,21 @@ __device__ __forceinline__ void dft8p(P2 (&x)[8]) {
   for (int j = 0; j < 8; ++j) x[j] = {u[j], v[j]};
 }
 
-// x *= 2^s with s uniform over the wavefront (scalar branches inside mul_pow2)
-__device__ __forceinline__ P2 shift_uniform(P2 x, uint32_t s) {
+// x *= 2^s with s uniform over the wavefront.  The multiplier 2^s mod P is built on the scalar unit
+// (s < 64: 1 << s; 64 <= s < 96: 2^(s-64) * (2^32 - 1); s >= 96: negated) and applied with a general
+// multiply: branch-free straight-line code schedules far better than a per-value choice among the
+// shift cases of mul_pow2, and the four multiply-adds are the cheap part of a GF(P) multiply anyway
+// (DESIGN.md section 5).
+__device__ __forceinline__ uint64_t pow2_uniform(uint32_t s) {
   s = __builtin_amdgcn_readfirstlane(s);
-  return {gf::mul_pow2(x.a, s), gf::mul_pow2(x.b, s)};
+  const bool neg = s >= 96;
+  const uint32_t r = neg ? s - 96 : s;
+  const uint64_t v = (r < 64) ? (uint64_t(1) << r) : ((uint64_t(1) << (r - 32)) - (uint64_t(1) << (r - 64)));
+  return neg ? gf::P - v : v;
+}
+__device__ __forceinline__ P2 shift_uniform(P2 x, uint32_t s) {
+  const uint64_t c = pow2_uniform(s);
+  return {gf::mul(x.a, c), gf::mul(x.b, c)};
 }
 
 // omega_m^e from the two-level table (e < m)
