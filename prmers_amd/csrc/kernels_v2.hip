@@ -115,6 +115,12 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 4096;
   P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * 4096;
   P2 x[8];
+  // table words of the pointwise stage, requested first: their latency hides behind the forward transform
+  const uint32_t kb = (lane >> 3) + 8 * (lane & 7) + 64 * wave;   // S4 thread (k3|k1|k2): frequency base k1 + 8 k2 + 64 k3
+  const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;       // column-DFT slot -> frequency (kernels.hip freq1)
+  const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * kb;
+  const uint64_t rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)], rho_hi = pl.TWhi[erho >> pl.twh];
 
   // ---- forward ----
 #pragma unroll
@@ -125,14 +131,17 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   dft8p<false>(x);
 #pragma unroll
   for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (gf::LOG2_W64 * k * wave) % 192);
-  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
-  dft8p<false>(x);
+  uint64_t sw[8];   // seam twiddles: loaded before the exchange so that their latency hides behind it
   {
     const uint32_t k1 = t & 7, b = t >> 3;
     const uint64_t* __restrict__ tw = pl.S2r + b * 64 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[8 * k2]);
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[8 * k2];
   }
+  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  dft8p<false>(x);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false>(x);
 #pragma unroll
@@ -153,11 +162,7 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
 
   // ---- pointwise: reg k4 holds X[kb + 512 k4]; rho = omega_m^(k1row + M1 k) = rho0 * omega_8^k4 ----
   {
-    const uint32_t kb = (lane >> 3) + 8 * (lane & 7) + 64 * wave;
-    // column-DFT slot -> frequency (same map as kernels.hip freq1; this kernel is used with r5 == 1 or 5)
-    const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;
-    const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
-    const uint64_t rho0 = tw_lookup(pl, uint64_t(k1row) + uint64_t(pl.M1) * kb);
+    const uint64_t rho0 = gf::mul(rho_lo, rho_hi);
     const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * 4096;
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
@@ -193,13 +198,15 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
 #pragma unroll
   for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (192 - (gf::LOG2_W64 * k * wave) % 192) % 192);
   dft8p<true>(x);
-  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
   {
     const uint32_t k1 = t & 7, b = t >> 3;
     const uint64_t* __restrict__ tw = pl.S2ri + b * 64 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[8 * k2]);
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[8 * k2];
   }
+  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   dft8p<true>(x);
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
 #pragma unroll
@@ -275,14 +282,23 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
 #pragma unroll
     for (int c = 0; c < 4; ++c) x[4 + c] = shift_uniform(x[4 + c], s);
   }
-  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
-  dft8p<false>(x);
+  uint64_t sw[8];   // seam twiddles, requested before the exchange that hides their latency
   {
     const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
     const uint64_t* __restrict__ tw = pl.S1r + b * 16 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[2 * k2]);
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[2 * k2];
   }
+  EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  dft8p<false>(x);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
+  // four-step twiddle ingredients for the last stage (thread (k3|k1|k2|c)), requested two exchanges early
+  const uint32_t fc = t & 3, fkb = ((t >> 5) & 1) + 2 * ((t >> 2) & 7) + 16 * (t >> 6), fi2 = 4 * T + fc;
+  const uint64_t feA = (uint64_t(fi2) * fkb) % pl.m, feB = (uint64_t(fi2) * 128) % pl.m;
+  const uint64_t fAl = pl.TWlo[feA & ((1u << pl.twh) - 1)], fAh = pl.TWhi[feA >> pl.twh];
+  const uint64_t fBl = pl.TWlo[feB & ((1u << pl.twh) - 1)], fBh = pl.TWhi[feB >> pl.twh];
+  const uint64_t fTB0 = pl.TB[2 * fi2], fTB1 = pl.TB[2 * fi2 + 1];
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false>(x);
 #pragma unroll
@@ -299,12 +315,10 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   }
   dft8p<false>(x);
   {
-    const uint32_t c = t & 3, k2 = (t >> 2) & 7, k1 = (t >> 5) & 1, k3 = t >> 6;
-    const uint32_t kb = k1 + 2 * k2 + 16 * k3;
-    const uint32_t i2 = 4 * T + c;
-    const uint64_t A = tw_lookup(pl, (uint64_t(i2) * kb) % pl.m);
-    const uint64_t B = tw_lookup(pl, (uint64_t(i2) * 128) % pl.m);
-    uint64_t ca = gf::mul(A, pl.TB[2 * i2]), cb = gf::mul(A, pl.TB[2 * i2 + 1]);
+    const uint32_t kb = fkb, i2 = fi2;
+    const uint64_t A = gf::mul(fAl, fAh);
+    const uint64_t B = gf::mul(fBl, fBh);
+    uint64_t ca = gf::mul(A, fTB0), cb = gf::mul(A, fTB1);
     const uint32_t row0 = __brev(kb) >> 22;   // bitrev10(kb): low 3 bits are zero
     P2* W = reinterpret_cast<P2*>(Wout);
 #pragma unroll
@@ -358,14 +372,20 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
 #pragma unroll
   for (int k = 1; k < 8; ++k) x[k] = shift_uniform(x[k], (192 - (gf::LOG2_W64 * k * wave) % 192) % 192);
   dft8p<true>(x);
-  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+  uint64_t sw[8];
   {
     const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
     const uint64_t* __restrict__ tw = pl.S1ri + b * 16 + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], tw[2 * k2]);
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[2 * k2];
   }
+  EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   dft8p<true>(x);
+  // unweighting tables of the carry phase (thread (d2|d3|d4): runs i1 = t, 512 + t), requested one exchange early
+  const uint32_t bsa0 = pl.SA[t], bsa1 = pl.SA[512 + t];
+  const uint64_t btai0 = pl.TAi[t], btai1 = pl.TAi[512 + t];
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
   {
     const uint32_t s = (192 - (4 * gf::LOG2_W64 * wave) % 192) % 192;
@@ -380,9 +400,8 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   }
 #pragma unroll
   for (int d1 = 0; d1 < 2; ++d1) {
-    const uint32_t i1 = 512 * d1 + t;
-    const uint32_t sa = pl.SA[i1];
-    const uint64_t tai = pl.TAi[i1];
+    const uint32_t sa = d1 ? bsa1 : bsa0;
+    const uint64_t tai = d1 ? btai1 : btai0;
     uint64_t carry = carry0[d1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
