@@ -85,6 +85,15 @@ def main():
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:   # the collective is a 24-byte status word; if RCCL cannot come up, do not lose the measurement
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:   # pragma: no cover - needs a broken fabric
+                sys.stderr.write("[bench] RCCL unavailable (%s); status reduction falls back to gloo\n" % exc)
+                dist.destroy_process_group()
+                dist.init_process_group("gloo")
+                red_dev, args.dist_backend = "cpu", "gloo (RCCL init failed)"
         else:
             dist.init_process_group(args.dist_backend)
 
@@ -147,6 +156,7 @@ def main():
             "config": {"workload": "square_mul x<-x^2 mod 2^p-1, p=%d, n=%d words" % (p, n),
                        "plan": __import__("prmers_amd").resolve_plan(p, args.plan),
                        "exponents": EXPONENTS[:world] if not args.exponent else [p],
+                       "status_reduction_backend": args.dist_backend if world > 1 else None,
                        "parallelism": "replicas: one exponent per GPU, no data-path collective" +
                                       (" [REHEARSAL: all ranks on one device]" if rehearsal else "")},
             "event_ms_per_step": round(ev_ms / args.steps, 5),
