@@ -84,14 +84,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             try:   # the collective is a 24-byte status word; if RCCL cannot come up, do not lose the measurement
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
             except Exception as exc:   # pragma: no cover - needs a broken fabric
                 sys.stderr.write("[bench] RCCL unavailable (%s); status reduction falls back to gloo\n" % exc)
-                dist.destroy_process_group()
+                if dist.is_initialized():
+                    dist.destroy_process_group()
                 dist.init_process_group("gloo")
                 red_dev, args.dist_backend = "cpu", "gloo (RCCL init failed)"
         else:
