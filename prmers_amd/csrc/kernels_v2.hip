@@ -411,10 +411,16 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
       uint64_t u = gf::mul((k & 1) ? v.b : v.a, tai);
       if (wrap) u = gf::dbl(u);
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
-      const uint64_t dlo = u & mask, chi = u >> width;
-      const uint64_t r = dlo * a + carry;
-      dg[d1][k] = uint32_t(r & mask);
-      carry = (r >> width) + chi * a;
+      if (a == 1) {               // the common case (uniform): no 64-bit multiplies
+        const uint64_t r = u + carry;                      // u < P, carry < 2^48: no wrap
+        dg[d1][k] = uint32_t(r & mask);
+        carry = r >> width;
+      } else {
+        const uint64_t dlo = u & mask, chi = u >> width;
+        const uint64_t r = dlo * a + carry;
+        dg[d1][k] = uint32_t(r & mask);
+        carry = (r >> width) + chi * a;
+      }
     }
     cout[d1] = carry;
   }
