@@ -303,6 +303,35 @@ def test_c4_205271257_full_size_radix5():
         assert e.res64(0) == o.res64(0)
 
 
+@pytest.mark.parametrize("p,n", [(332000003, 5 << 22), (600000001, 1 << 25), (700000001, 5 << 23)])
+def test_largest_supported_transforms(p, n):
+    """the largest shapes the plan accepts (rows of 8192 = 128 KiB of LDS, columns of 2048 and 2560):
+    squarings with a factor and a mul against the oracle's digit vectors."""
+    o = orc.Oracle(p, 3)
+    assert o.n == n
+    rng = np.random.default_rng(p)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 4) as e:
+        assert e.n == n
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        for a in (1, 3):
+            e.square_mul(0, a); o.square_mul(0, a)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.copy(1, 0); o.copy(1, 0)
+        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)
+        e.sub(0, 2); o.sub(0, 2)
+        e.mul(0, 2); o.mul(0, 2)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert e.res64(0) == o.res64(0)
+
+
+def test_unsupported_transform_size_is_refused():
+    """n > 5*2^23 needs a third transform level this round does not have: creation fails loudly."""
+    with pytest.raises(Exception, match="not supported"):
+        Engine(800000011, 2)
+
+
 @pytest.mark.parametrize("p,plan", [(300007, "m2=8,c=4"), (136279841, None)])
 def test_fused_back_front_sweep(p, plan, monkeypatch):
     """MI355_FUSED=1: the residue stays a front image between squarings (inter-work-group carry hand-off);
