@@ -28,8 +28,18 @@ GF_HD uint64_t add(uint64_t a, uint64_t b) {
 }
 
 GF_HD uint64_t sub(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the borrow comes out of the 32-bit subtract-with-borrow pair itself (one 64-bit compare less than
+  // the portable form); d - EPS == d + P (mod 2^64)
+  unsigned c0, c1;
+  uint32_t lo = __builtin_subc((uint32_t)a, (uint32_t)b, 0u, &c0);
+  uint32_t hi = __builtin_subc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c0, &c1);
+  uint64_t d = ((uint64_t)hi << 32) | lo;
+  return d + (c1 ? P : 0ull);
+#else
   uint64_t d = a - b;
   return d - ((a < b) ? EPS : 0ull);
+#endif
 }
 
 GF_HD uint64_t neg(uint64_t a) { return a ? P - a : 0ull; }

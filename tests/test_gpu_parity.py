@@ -357,3 +357,12 @@ def test_fused_back_front_sweep(p, plan, monkeypatch):
         assert np.array_equal(e.digits(0), o.digits(0))
         assert np.array_equal(e.digits(1), o.digits(1))
         e.sync()
+
+
+@pytest.mark.parametrize("p", [9815459, 136279841, 205271257])
+def test_gmp_pins_at_baseline_exponents(p):
+    """C2 / C3 / C4 from x0 = 3: res64, low 2048 bits and the SHA-256 of the canonical words at iterations
+    30.. against the GMP-generated fixture (tests/golden/big_p_pins.json) -- no oracle involved."""
+    from test_oracle_golden import check_pins
+    with Engine(p, 2) as e:
+        check_pins(e, p)

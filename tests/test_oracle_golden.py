@@ -247,3 +247,31 @@ def test_digit_formatting_matches_reference_headers(p):
             o.set_value(1, v)
             assert orc.digits_to_int(o.digits(1)) == v
             assert dref.size == o.n
+
+
+PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "big_p_pins.json")))
+
+
+def check_pins(eng, p):
+    """run 3 -> 3^(2^it) and compare res64, the low 2048 bits and the SHA-256 of the canonical word vector
+    with the GMP-generated pins (SURVEY.md 8c 'Big-p pins', tests/golden/make_big_p_pins.py)."""
+    import hashlib
+    pins = {e["iteration"]: e for e in PINS["pins"][str(p)]}
+    eng.set(0, 3)
+    for it in range(1, max(pins) + 1):
+        eng.square_mul(0)
+        if it in pins:
+            w = np.ascontiguousarray(eng.words(0), dtype="<u4")
+            e = pins[it]
+            assert "%016X" % eng.res64(0) == e["res64"], (p, it)
+            assert w.tobytes()[:256][::-1].hex().upper() == e["low2048"], (p, it)
+            assert hashlib.sha256(w.tobytes()).hexdigest() == e["sha256_words"], (p, it)
+
+
+@pytest.mark.parametrize("p", [9815459, 136279841, 205271257])
+def test_oracle_matches_gmp_pins_at_baseline_exponents(p):
+    """C2 / C3 / C4: the oracle agrees with GMP on full-size operands (iterations 30..36/42 of the PRP
+    sequence from 3), so oracle-vs-engine parity at these sizes is anchored outside this repo's code."""
+    o = orc.Oracle(p, 1)
+    check_pins(o, p)
+    o.close()
