@@ -114,10 +114,14 @@ GF_HD uint64_t mul_pow2(uint64_t a, unsigned s) {
     const uint64_t lo = a << s, hi = a >> (64 - s);
     r = add(lo, (hi << 32) - hi);
   } else if (s < 64) {
-    // a*2^s = top*2^96 + mid*2^64 + lo:  lo + mid*(2^32-1) - top
-    const uint64_t lo = a << s, h = a >> (64 - s);
-    const uint64_t mid = h & 0xffffffffull, top = h >> 32;
-    r = sub(add(lo, (mid << 32) - mid), top);
+    // a*2^s = top*2^96 + mid*2^64 + lh*2^32 (the low word of a << s is zero)
+    //       = (lh + mid)*2^32 - (mid + top).  The 33-bit sum lh + mid = c*2^32 + xhi folds its carry as
+    // c*2^64 = c*(2^32-1) into the empty low word, which leaves a canonical value; one sub() finishes.
+    const uint64_t h = a >> (64 - s);
+    const uint32_t lh = (uint32_t)a << (s - 32), mid = (uint32_t)h, top = (uint32_t)(h >> 32);
+    const uint32_t xhi = lh + mid;
+    const uint64_t x = ((uint64_t)xhi << 32) | ((xhi < lh) ? 0xffffffffu : 0u);
+    r = sub(x, (uint64_t)mid + top);
   } else if (s == 64) {
     const uint64_t ah = a >> 32, al = a & 0xffffffffull;
     r = sub((al << 32) - al, ah);
