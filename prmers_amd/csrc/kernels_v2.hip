@@ -118,7 +118,7 @@ __device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
 }
 
 __device__ __forceinline__ void digit_info(const DevPlan& pl, uint32_t sa, uint32_t sb, uint32_t& width, bool& wrap) {
-  uint64_t s = uint64_t(sa) + sb;
+  uint32_t s = sa + sb;   // sa, sb < n <= 5*2^23: 32-bit arithmetic suffices
   wrap = (sa > 0) && (sb > 0) && (s <= pl.n);
   if (s >= pl.n) s -= pl.n;
   width = pl.q + ((s + pl.t > 0) ? 1u : 0u) + ((s + pl.t > pl.n) ? 1u : 0u) - ((s > 0) ? 1u : 0u);
@@ -301,15 +301,15 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   for (int d1 = 0; d1 < 2; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
     const uint32_t sa = pl.SA[i1];
-    const uint64_t ta = pl.TA[i1];
+    const uint64_t tah = gf::half(pl.TA[i1]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       uint32_t w0, w1; bool wr0, wr1;
       digit_info(pl, sa, pl.SB[8 * T + 2 * c], w0, wr0);
       digit_info(pl, sa, pl.SB[8 * T + 2 * c + 1], w1, wr1);
-      uint64_t a0 = gf::mul_u32(ta, dg[d1][2 * c]), a1 = gf::mul_u32(ta, dg[d1][2 * c + 1]);
-      if (wr0) a0 = gf::half(a0);
-      if (wr1) a1 = gf::half(a1);
+      // weight TA*TB, halved when the exponents wrap: the halving is moved onto TA (once per run) and
+      // the un-wrapped digits are doubled instead (digits are < 2^21, the product stays a mul_u32)
+      const uint64_t a0 = gf::mul_u32(tah, dg[d1][2 * c] << (wr0 ? 0 : 1)), a1 = gf::mul_u32(tah, dg[d1][2 * c + 1] << (wr1 ? 0 : 1));
       x[4 * d1 + c] = {a0, a1};
     }
     if (sub != 0 && T == 0 && i1 == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));   // digit 0 has weight 1
@@ -433,14 +433,14 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   for (int d1 = 0; d1 < 2; ++d1) {
     const uint32_t sa = d1 ? bsa1 : bsa0;
     const uint64_t tai = d1 ? btai1 : btai0;
+    const uint64_t tai2 = gf::dbl(tai);
     uint64_t carry = carry0[d1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       uint32_t width; bool wrap;
       digit_info(pl, sa, pl.SB[8 * T + k], width, wrap);
       const P2 v = x[4 * d1 + (k >> 1)];
-      uint64_t u = gf::mul((k & 1) ? v.b : v.a, tai);
-      if (wrap) u = gf::dbl(u);
+      const uint64_t u = gf::mul((k & 1) ? v.b : v.a, wrap ? tai2 : tai);   // wrapped exponents: weight was halved
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
       if (a == 1) {               // the common case (uniform): no 64-bit multiplies
         const uint64_t r = u + carry;                      // u < P, carry < 2^48: no wrap
