@@ -300,16 +300,17 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
 #pragma unroll
   for (int d1 = 0; d1 < 2; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
-    const uint32_t sa = pl.SA[i1];
-    const uint64_t tah = gf::half(pl.TA[i1]);
+    const uint32_t sa = pl.SA[i1], sa1 = pl.SA[1024 + i1];       // odd digits: exponent split SA[M1 + i1] + SB[2 i2]
+    const uint64_t tah = gf::half(pl.TA[i1]), tah1 = gf::half(pl.TA[1024 + i1]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       uint32_t w0, w1; bool wr0, wr1;
-      digit_info(pl, sa, pl.SB[8 * T + 2 * c], w0, wr0);
-      digit_info(pl, sa, pl.SB[8 * T + 2 * c + 1], w1, wr1);
+      const uint32_t sb = pl.SB[8 * T + 2 * c];
+      digit_info(pl, sa, sb, w0, wr0);
+      digit_info(pl, sa1, sb, w1, wr1);
       // weight TA*TB, halved when the exponents wrap: the halving is moved onto TA (once per run) and
       // the un-wrapped digits are doubled instead (digits are < 2^21, the product stays a mul_u32)
-      const uint64_t a0 = gf::mul_u32(tah, dg[d1][2 * c] << (wr0 ? 0 : 1)), a1 = gf::mul_u32(tah, dg[d1][2 * c + 1] << (wr1 ? 0 : 1));
+      const uint64_t a0 = gf::mul_u32(tah, dg[d1][2 * c] << (wr0 ? 0 : 1)), a1 = gf::mul_u32(tah1, dg[d1][2 * c + 1] << (wr1 ? 0 : 1));
       x[4 * d1 + c] = {a0, a1};
     }
     if (sub != 0 && T == 0 && i1 == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));   // digit 0 has weight 1
@@ -339,7 +340,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   const uint64_t feA = (uint64_t(fi2) * fkb) % pl.m, feB = (uint64_t(fi2) * 128) % pl.m;
   const uint64_t fAl = pl.TWlo[feA & ((1u << pl.twh) - 1)], fAh = pl.TWhi[feA >> pl.twh];
   const uint64_t fBl = pl.TWlo[feB & ((1u << pl.twh) - 1)], fBh = pl.TWhi[feB >> pl.twh];
-  const uint64_t fTB0 = pl.TB[2 * fi2], fTB1 = pl.TB[2 * fi2 + 1];
+  const uint64_t fTB0 = pl.TB[2 * fi2];
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false>(x);
   seam64<false>(x, wave);
@@ -358,14 +359,14 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
     const uint32_t kb = fkb, i2 = fi2;
     const uint64_t A = gf::mul(fAl, fAh);
     const uint64_t B = gf::mul(fBl, fBh);
-    uint64_t ca = gf::mul(A, fTB0), cb = gf::mul(A, fTB1);
+    uint64_t ca = gf::mul(A, fTB0);   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
     const uint32_t row0 = __brev(kb) >> 22;   // bitrev10(kb): low 3 bits are zero
     P2* W = reinterpret_cast<P2*>(Wout);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t rj = ((j & 1) << 2) | (j & 2) | (j >> 2);   // bitrev3(j)
-      W[size_t(row0 + rj) * pl.M2 + i2] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, cb)};
-      if (j < 7) { ca = gf::mul(ca, B); cb = gf::mul(cb, B); }
+      W[size_t(row0 + rj) * pl.M2 + i2] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)};
+      if (j < 7) ca = gf::mul(ca, B);
     }
   }
 }
@@ -385,7 +386,7 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
     uint64_t A = tw_lookup(pl, ea ? pl.m - ea : 0);
     const uint64_t B = tw_lookup(pl, eb ? pl.m - eb : 0);
     if (scale != 1) A = gf::mul(A, scale);
-    uint64_t ca = gf::mul(A, pl.TBi[2 * i2]), cb = gf::mul(A, pl.TBi[2 * i2 + 1]);
+    uint64_t ca = gf::mul(A, pl.TBi[2 * i2]);   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
     const uint32_t row0 = __brev(kb) >> 22;
     const P2* W = reinterpret_cast<const P2*>(Win);
 #pragma unroll
@@ -395,8 +396,8 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      x[j] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, cb)};
-      if (j < 7) { ca = gf::mul(ca, B); cb = gf::mul(cb, B); }
+      x[j] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)};
+      if (j < 7) ca = gf::mul(ca, B);
     }
   }
   dft8p<true>(x);
@@ -423,24 +424,24 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   dft8p<true>(x);
   // unweighting tables of the carry phase (thread (d2|d3|d4): runs i1 = t, 512 + t), requested one exchange early
-  const uint32_t bsa0 = pl.SA[t], bsa1 = pl.SA[512 + t];
-  const uint64_t btai0 = pl.TAi[t], btai1 = pl.TAi[512 + t];
+  const uint32_t bsa0 = pl.SA[t], bsa1 = pl.SA[512 + t], bsb0 = pl.SA[1024 + t], bsb1 = pl.SA[1536 + t];   // odd digits: second half
+  const uint64_t btai0 = pl.TAi[t], btai1 = pl.TAi[512 + t], btbi0 = pl.TAi[1024 + t], btbi1 = pl.TAi[1536 + t];
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
 #define MI355_CALL(W) seam16_inv_butterfly_const<W>(x)
   MI355_SWITCH8(wave, MI355_CALL)
 #undef MI355_CALL
 #pragma unroll
   for (int d1 = 0; d1 < 2; ++d1) {
-    const uint32_t sa = d1 ? bsa1 : bsa0;
-    const uint64_t tai = d1 ? btai1 : btai0;
-    const uint64_t tai2 = gf::dbl(tai);
+    const uint32_t sa_e = d1 ? bsa1 : bsa0, sa_o = d1 ? bsb1 : bsb0;
+    const uint64_t tai_e = d1 ? btai1 : btai0, tai_o = d1 ? btbi1 : btbi0;
+    const uint64_t tai2_e = gf::dbl(tai_e), tai2_o = gf::dbl(tai_o);
     uint64_t carry = carry0[d1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       uint32_t width; bool wrap;
-      digit_info(pl, sa, pl.SB[8 * T + k], width, wrap);
+      digit_info(pl, (k & 1) ? sa_o : sa_e, pl.SB[8 * T + (k & ~1)], width, wrap);
       const P2 v = x[4 * d1 + (k >> 1)];
-      const uint64_t u = gf::mul((k & 1) ? v.b : v.a, wrap ? tai2 : tai);   // wrapped exponents: weight was halved
+      const uint64_t u = (k & 1) ? gf::mul(v.b, wrap ? tai2_o : tai_o) : gf::mul(v.a, wrap ? tai2_e : tai_e);   // wrapped exponents: weight was halved
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
       if (a == 1) {               // the common case (uniform): no 64-bit multiplies
         const uint64_t r = u + carry;                      // u < P, carry < 2^48: no wrap

@@ -162,9 +162,13 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   const uint64_t om = gf::root_of_unity(m);
   const uint64_t inv_m = gf::inv(uint64_t(m) % gf::P);
 
-  pl.SA.resize(pl.M1); pl.TA.resize(pl.M1); pl.TAi.resize(pl.M1);
-  for (uint32_t i1 = 0; i1 < pl.M1; ++i1) {
-    const uint64_t s = (uint64_t(2) * pl.M2 % n * (uint64_t(p) % n) % n * i1) % n;
+  // entries [0, M1): digit 2*(M2*i1 + i2) + b split as SA[i1] + SB[2*i2 + b];  entries [M1, 2*M1): the odd
+  // digit's "+p" moved to the i1 side, SA[M1 + i1] + SB[2*i2], so that both digits of a pair share the
+  // column factor TB[2*i2] (the register-resident column kernels fold it into one four-step twiddle chain)
+  pl.SA.resize(2 * size_t(pl.M1)); pl.TA.resize(2 * size_t(pl.M1)); pl.TAi.resize(2 * size_t(pl.M1));
+  for (uint32_t i1 = 0; i1 < 2 * pl.M1; ++i1) {
+    const uint64_t s0 = (uint64_t(2) * pl.M2 % n * (uint64_t(p) % n) % n * (i1 % pl.M1)) % n;
+    const uint64_t s = (i1 < pl.M1) ? s0 : (s0 + pl.t) % n;
     pl.SA[i1] = uint32_t(s);
     pl.TA[i1] = gf::pow(r, (n - s) % n);
     pl.TAi[i1] = gf::mul(gf::inv(pl.TA[i1]), inv_m);
