@@ -4,7 +4,8 @@ Mirror of the reference's Marin-path driver (src/modes/RunPrpOrLlMarin.cpp:97-77
 the Gerbicz-Li check and rollback (:338-412), the `-erroriter` fault injection (:326-336), LL-unsafe
 (x^2-2, :321-324), checkpoint files (:156-211 with the CRC of include/marin/file.h:49-111), result
 formatting (include/core/AlgoUtils.hpp:165-223) and the worktodo line formats
-(src/io/WorktodoParser.cpp:78-400) used to shard exponents one per GPU.
+(src/io/WorktodoParser.cpp:78-400) used to shard exponents one per GPU; plus the LL-safe
+driver with block re-computation (src/modes/RunLlSafeMarin.cpp:96-360).
 
 Everything here talks to an engine only through its interface (set / copy / square_mul / sub /
 set_multiplicand / mul / get_int / digits / get_checkpoint / set_checkpoint), so the same driver runs
@@ -255,6 +256,81 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     return {"exponent": p, "mode": mode, "is_prime": bool(is_prime) and it >= total, "res64": format_res64(words),
             "res2048": format_res2048(words), "iterations": it, "gerbicz_checks": checks,
             "gerbicz_errors": errors, "complete": it >= total}
+
+
+# register roles of the LL-safe driver (RunLlSafeMarin.cpp:20-28: V, U, their last good copies, the re-run copies)
+LS_RV, LS_RU, LS_RVC, LS_RUC, LS_RVCHK, LS_RUCHK, LS_RTMP = range(7)
+
+
+def run_ll_safe(eng, p, block=0, erroriter=0, max_iters=None, log=None):
+    """Lucas-Lehmer with error detection by block re-computation -- mirror of LL-safe mode
+    (RunLlSafeMarin.cpp:96-360).  V follows x -> x^2 - 2 from 4; U accumulates the product of the V's
+    (set_multiplicand + mul per iteration, :257-260); every B = p / sqrt(p) iterations (or `block`, the
+    reference's -llsafe_block) the block is recomputed from the last good (V, U) and both pairs must agree
+    (:268-296), otherwise the state rolls back to the block start (:297-318).  erroriter injects V -= 2
+    once, like the reference's -erroriter (:245-255).  Needs >= 8 registers."""
+    log = log or (lambda m: None)
+    total = p - 2 if p >= 2 else 0
+    eng.set(LS_RV, 4)
+    eng.set(LS_RU, 2)
+    eng.copy(LS_RVC, LS_RV)
+    eng.copy(LS_RUC, LS_RU)
+    eng.copy(LS_RVCHK, LS_RVC)
+    eng.copy(LS_RUCHK, LS_RUC)
+    B = int(block) if block > 0 else int(p / math.sqrt(float(p)))
+    B = min(max(B, 1), max(total, 1))
+
+    def step(rv, ru):
+        eng.set_multiplicand(LS_RTMP, rv)
+        eng.mul(ru, LS_RTMP)
+        eng.square_mul(rv)
+        eng.sub(rv, 2)
+
+    errordone = False
+    itersave = 0
+    checks = errors = done = 0
+    it = 0
+    while it < total:
+        if max_iters is not None and done >= max_iters:
+            break
+        if erroriter > 0 and it + 1 == erroriter and not errordone:
+            errordone = True
+            eng.sub(LS_RV, 2)
+            log("Injected error at iteration %d" % (it + 1))
+        step(LS_RV, LS_RU)
+        done += 1
+        if (it + 1) % B == 0 or it + 1 == total:
+            blk = B if (it + 1) % B == 0 else (it + 1) - itersave
+            eng.copy(LS_RVCHK, LS_RVC)
+            eng.copy(LS_RUCHK, LS_RUC)
+            for _ in range(blk):
+                step(LS_RVCHK, LS_RUCHK)
+            checks += 1
+            ok = eng.get_int(LS_RVCHK) == eng.get_int(LS_RV) and eng.get_int(LS_RUCHK) == eng.get_int(LS_RU)
+            if not ok:
+                log("[Error check] Mismatch")
+                log("[Error check] Check FAILED! iter=%d" % it)
+                log("[Error check] Restore iter=%d" % itersave)
+                errors += 1
+                eng.copy(LS_RV, LS_RVC)
+                eng.copy(LS_RU, LS_RUC)
+                it = itersave
+                continue
+            log("[Error check] Check passed! iter=%d" % it)
+            eng.copy(LS_RVC, LS_RV)
+            eng.copy(LS_RUC, LS_RU)
+            itersave = it + 1
+        it += 1
+
+    d = eng.digits(LS_RV)
+    is_mp = digits_equal_to_Mp(d)
+    is_prime = (digits_equal_to(d, 0) or is_mp) and it >= total
+    words = pack_words(d, p)
+    if is_prime and is_mp:
+        words[:] = 0          # the all-ones vector stands for 0 (RunLlSafeMarin.cpp:335-338)
+    return {"exponent": p, "mode": "llsafe", "is_prime": bool(is_prime), "res64": format_res64(words),
+            "res2048": format_res2048(words), "iterations": it, "checks": checks, "errors": errors,
+            "complete": it >= total}
 
 
 def result_json(r, fft_length, program_version="mi355-marin-hip 0.1", port=8, user="", computer="", aid="", timestamp=""):

@@ -146,3 +146,33 @@ def test_result_json_shape():
         r = prp.run_prp_or_ll(e, 1001, "ll")
         d = json.loads(prp.result_json(r, e.get_size()))
     assert d["status"] == "C" and d["worktype"] == "LL" and "res2048" not in d
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("p,prime", [(127, True), (521, True), (607, True), (1001, False), (2203, True)])
+def test_ll_safe_block_recomputation(kind, p, prime):
+    """LL-safe (RunLlSafeMarin.cpp:96-360): V, U = prod V, block re-computation check; answer vs Python ints."""
+    msgs = []
+    with make_engine(kind, p) as e:
+        r = prp.run_ll_safe(e, p, log=msgs.append)
+    s, M = 4, (1 << p) - 1
+    for _ in range(p - 2):
+        s = (s * s - 2) % M
+    assert r["complete"] and r["is_prime"] == prime == (s == 0) and r["errors"] == 0 and r["checks"] >= 1
+    assert r["res64"] == "%016X" % (s & (2**64 - 1))
+    assert sum(m.startswith("[Error check] Check passed!") for m in msgs) == r["checks"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("erroriter", [1, 50, 300, 1277])
+def test_ll_safe_detects_and_repairs_injected_error(kind, erroriter):
+    """-erroriter N in LL-safe mode: the block check fails once, the state rolls back to the block start
+    and the run still ends on the right answer (M1279 is prime)."""
+    p, msgs = 1279, []
+    with make_engine(kind, p) as e:
+        r = prp.run_ll_safe(e, p, erroriter=erroriter, log=msgs.append)
+    B = int(p / (p ** 0.5))
+    blk_start = ((erroriter - 1) // B) * B
+    assert r["is_prime"] and r["errors"] == 1 and r["res64"] == "0" * 16
+    assert "Injected error at iteration %d" % erroriter in msgs
+    assert "[Error check] Restore iter=%d" % blk_start in msgs
