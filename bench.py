@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 # transform size per GPU for the multi-GPU runs (worktodo-style sharding, configs[4])
 EXPONENTS = [136279841, 136279879, 136279901, 136279919, 136279933, 136279967, 136279981, 136279987]
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0   # the guide's measured copy ceiling (SURVEY.md 8d asks for both)
 
 
 def seeded_digits(p, n, seed):
@@ -163,6 +164,8 @@ def main():
             "event_ms_per_step": round(ev_ms / args.steps, 5),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
+                         "binding_roof": "VALU issue (integer GF(P) arithmetic), see DESIGN.md section 5",
                          "algorithmic_bytes_per_launch": sweep_bytes,
                          "kernel_ms": {k: round(v, 5) for k, v in kern.items()},
                          "iteration": {"algorithmic_bytes": 48 * n,
