@@ -125,6 +125,10 @@ def main():
         dist.all_reduce(status, op=dist.ReduceOp.SUM)   # the only cross-GPU traffic: a 24-byte status word
     elapsed = float(tmax.item())
 
+    # BASELINE configs[2] is the LL form of the same exponent (x^2 - 2): a short untimed-region measurement
+    # of that variant, reported beside the metric (the subtraction rides on the next front sweep)
+    ll_iters = min(args.steps, 500)
+    ll_ms, _ = eng.time_square_mul(0, ll_iters, sub=2)
     # second, instrumented pass of the same loop: per-kernel durations from event pairs on the engine stream
     _, kern = eng.time_square_mul(0, min(args.steps, 64), per_kernel=True)
     if rank == 0:
@@ -162,6 +166,7 @@ def main():
                        "parallelism": "replicas: one exponent per GPU, no data-path collective" +
                                       (" [REHEARSAL: all ranks on one device]" if rehearsal else "")},
             "event_ms_per_step": round(ev_ms / args.steps, 5),
+            "ll_ms_per_step": round(ll_ms / ll_iters, 5),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),

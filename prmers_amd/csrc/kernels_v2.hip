@@ -155,8 +155,9 @@ __device__ __forceinline__ uint32_t tile_of_block(const DevPlan& pl, uint32_t b,
 // pointwise in registers, then the mirror image back to natural order.
 // mode 0: square, 1: multiply by image Y, 2: forward only (writes the image).
 // ---------------------------------------------------------------------------------------------
+template <int mode>
 __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
-                                                      uint64_t* __restrict__ Wout, int mode, uint32_t sub) {
+                                                      uint64_t* __restrict__ Wout, uint32_t sub) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), row = blockIdx.x;
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 4096;
@@ -570,7 +571,11 @@ bool v2_rows_supported(const DevPlan& pl) { return pl.M2 == 4096; }
 bool v2_cols_supported(const DevPlan& pl) { return pl.M1 == 1024 && pl.r5 == 1 && pl.C == 4 && pl.M2 >= 8; }
 
 hipError_t v2_configure() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k1_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
   if (e != hipSuccess) return e;
@@ -579,7 +584,11 @@ hipError_t v2_configure() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k31_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes + 64));
 }
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
-  hipLaunchKernelGGL(v2::k2_rows4096, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, mode, sub);
+  switch (mode) {   // one instantiation per mode: the squaring kernel carries no multiply / image code
+    case 0: hipLaunchKernelGGL(v2::k2_rows4096<0>, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
+    case 1: hipLaunchKernelGGL(v2::k2_rows4096<1>, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
+    default: hipLaunchKernelGGL(v2::k2_rows4096<2>, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
+  }
   return hipGetLastError();
 }
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
