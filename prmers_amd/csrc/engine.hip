@@ -90,7 +90,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     // (measured at C3: 0.222 ms/iter fused vs 0.213 unfused -- the sweeps are VALU-bound, so saving the digit
     // round trip buys nothing yet; kept selectable with MI355_FUSED=1, off by default)
     const char* fz = std::getenv("MI355_FUSED");
-    fused_ = v2cols_ && fz && fz[0] == '1';
+    fused_ = v2cols_ && pl_.M1 == 1024 && fz && fz[0] == '1';
     if (fused_) {
       const size_t groups = pl_.M2 / 8;
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&cw_), groups * 1024 * 8));

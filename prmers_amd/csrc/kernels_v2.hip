@@ -76,29 +76,6 @@ __device__ __forceinline__ void seam64(P2 (&x)[8], uint32_t wave) {
   }
 }
 
-// omega_16 seam of the column kernels' radix-2 stage, same specialisation.  In the inverse direction the
-// butterfly follows the shift in the same thread, so a negative sign (shift >= 96) is absorbed by swapping
-// the sum and the difference.
-template <int W>
-__device__ __forceinline__ void seam16_fwd_const(P2 (&x)[8]) {
-  const unsigned s = (4u * gf::LOG2_W64 * unsigned(W)) % 192u;   // omega_16^d2 = omega_64^(4 d2)
-#pragma unroll
-  for (int c = 0; c < 4; ++c) x[4 + c] = {gf::mul_pow2(x[4 + c].a, s), gf::mul_pow2(x[4 + c].b, s)};
-}
-template <int W>
-__device__ __forceinline__ void seam16_inv_butterfly_const(P2 (&x)[8]) {
-  const unsigned f = (192u - (4u * gf::LOG2_W64 * unsigned(W)) % 192u) % 192u;
-  const bool neg = f >= 96u;
-  const unsigned s = neg ? f - 96u : f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const P2 u = x[c];
-    const P2 v = {gf::mul_pow2(x[4 + c].a, s), gf::mul_pow2(x[4 + c].b, s)};
-    const P2 sum = {gf::add(u.a, v.a), gf::add(u.b, v.b)}, dif = {gf::sub(u.a, v.a), gf::sub(u.b, v.b)};
-    x[c] = neg ? dif : sum;
-    x[4 + c] = neg ? sum : dif;
-  }
-}
 #define MI355_SWITCH8(w, CALL) \
   switch (w) {                 \
     case 0: CALL(0); break;    \
@@ -268,24 +245,99 @@ __device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Column tiles, M1 = 1024 = 2.8.8.8, C = 4.  Tile element (i1, c), i1 = 512 d1 + 64 d2 + 8 d3 + d4.
+// Column tiles, M1 = 512 R = R.8.8.8 with R in {1, 2, 4} and C = 8 / R pairs per run (tile = 4096 pairs).
+// Tile element (i1, c), i1 = 512 d1 + 64 d2 + 8 d3 + d4 (d1 < R).  kc = k1 C + c is a 3-bit register /
+// thread field throughout.
 // front_tile (digits -> work buffer):
-//   S1 thread (d2|d3|d4) regs (d1,c): two whole runs of 8 digits -> weight -> DFT2 -> k1 ; shift omega_16^(k1 d2)
-//   S2 thread (d3|d4|k1|c) regs d2 -> k2 ; general omega_1024^((k1+2k2)(8d3+d4))
+//   S1 thread (d2|d3|d4) regs (d1,c): R whole runs of 2C digits -> weight -> DFT_R -> k1 ; shift omega_8R^(k1 d2)
+//   S2 thread (d3|d4|k1|c) regs d2 -> k2 ; general omega_M1^((k1 + R k2)(8d3+d4))
 //   S3 thread (d4|k1|c|k2) regs d3 -> k3 ; shift omega_64^(k3 d4)
-//   S4 thread (k3|k1|k2|c) regs d4 -> k4 ; k1col = k1 + 2 k2 + 16 k3 + 128 k4
-//   then the four-step twiddle omega_m^(i2 k1col) * TB (geometric in k4: one chain multiply per element)
-//   and the store to work-buffer row bitrev10(k1col), column i2 = 4T + c.
-// back_tile is the mirror image, followed by unweight and the sequential carry of the thread's two runs.
+//   S4 thread (k3|k1|k2|c) regs d4 -> k4 ; k1col = k1 + R k2 + 8R k3 + 64R k4
+//   then the four-step twiddle omega_m^(i2 k1col) * TB (geometric in k4: one chain multiply per pair)
+//   and the store to work-buffer row bitrev(k1col), column i2 = C T + c.
+// back_tile is the mirror image, followed by unweight and the sequential carry of the thread's R runs.
 // ---------------------------------------------------------------------------------------------
 
+template <int R> struct ColShape {
+  static constexpr int C = 8 / R;                      // pairs per run
+  static constexpr int LC = (C == 8) ? 3 : (C == 4) ? 2 : 1;
+  static constexpr int LR = 3 - LC;
+  static constexpr int M1 = 512 * R, LM = 9 + LR, ND = 2 * C;   // digits per run
+};
+
+// out[k] = sum_j in[j] omega_4^(jk), omega_4 = 2^48 (forward; the inverse uses omega_4^-1 = -2^48), in place
+template <bool INV>
+__device__ __forceinline__ void dft4(uint64_t& x0, uint64_t& x1, uint64_t& x2, uint64_t& x3) {
+  const uint64_t a0 = gf::add(x0, x2), a1 = gf::add(x1, x3), b0 = gf::sub(x0, x2);
+  const uint64_t b1 = gf::mul_pow2(INV ? gf::sub(x3, x1) : gf::sub(x1, x3), 48);
+  x0 = gf::add(a0, a1); x2 = gf::sub(a0, a1); x1 = gf::add(b0, b1); x3 = gf::sub(b0, b1);
+}
+
+// S1 of the front: DFT_R over d1 (register slots d1 C + c -> k1 C + c), then x[k1 C + c] *= omega_8R^(k1 W)
+template <int R, int W>
+__device__ __forceinline__ void stage_r_fwd_const(P2 (&x)[8]) {
+  constexpr int C = 8 / R;
+  if (R == 2) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const P2 u = x[c], v = x[C + c];
+      x[c] = {gf::add(u.a, v.a), gf::add(u.b, v.b)};
+      x[C + c] = {gf::sub(u.a, v.a), gf::sub(u.b, v.b)};
+    }
+  } else if (R == 4) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      dft4<false>(x[c].a, x[C + c].a, x[2 * C + c].a, x[3 * C + c].a);
+      dft4<false>(x[c].b, x[C + c].b, x[2 * C + c].b, x[3 * C + c].b);
+    }
+  }
+#pragma unroll
+  for (int k1 = 1; k1 < R; ++k1) {
+    const unsigned s = ((8u / unsigned(R)) * gf::LOG2_W64 * unsigned(k1) * unsigned(W)) % 192u;   // omega_8R = omega_64^(8/R)
+#pragma unroll
+    for (int c = 0; c < C; ++c) x[k1 * C + c] = {gf::mul_pow2(x[k1 * C + c].a, s), gf::mul_pow2(x[k1 * C + c].b, s)};
+  }
+}
+// last stage of the back: the inverse seam, then the inverse DFT_R.  For R = 2 a negative sign (shift >= 96)
+// is absorbed by swapping the sum and the difference.
+template <int R, int W>
+__device__ __forceinline__ void stage_r_inv_const(P2 (&x)[8]) {
+  constexpr int C = 8 / R;
+  if (R == 2) {
+    const unsigned f = (192u - (4u * gf::LOG2_W64 * unsigned(W)) % 192u) % 192u;
+    const bool neg = f >= 96u;
+    const unsigned s = neg ? f - 96u : f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const P2 u = x[c];
+      const P2 v = {gf::mul_pow2(x[C + c].a, s), gf::mul_pow2(x[C + c].b, s)};
+      const P2 sum = {gf::add(u.a, v.a), gf::add(u.b, v.b)}, dif = {gf::sub(u.a, v.a), gf::sub(u.b, v.b)};
+      x[c] = neg ? dif : sum;
+      x[C + c] = neg ? sum : dif;
+    }
+  } else if (R == 4) {
+#pragma unroll
+    for (int k1 = 1; k1 < R; ++k1) {
+      const unsigned s = (192u - ((8u / unsigned(R)) * gf::LOG2_W64 * unsigned(k1) * unsigned(W)) % 192u) % 192u;
+#pragma unroll
+      for (int c = 0; c < C; ++c) x[k1 * C + c] = {gf::mul_pow2(x[k1 * C + c].a, s), gf::mul_pow2(x[k1 * C + c].b, s)};
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      dft4<true>(x[c].a, x[C + c].a, x[2 * C + c].a, x[3 * C + c].a);
+      dft4<true>(x[c].b, x[C + c].b, x[2 * C + c].b, x[3 * C + c].b);
+    }
+  }
+}
+
 // weak carry of a run's incoming carry word into its first digits (adc4, marin.cl:203-212)
-__device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t T, uint32_t i1, uint64_t cin, uint32_t (&d)[8]) {
+template <int ND>
+__device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t T, uint32_t i1, uint64_t cin, uint32_t (&d)[ND]) {
   const uint32_t sa = pl.SA[i1];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     uint32_t width; bool wr;
-    digit_info(pl, sa, pl.SB[8 * T + k], width, wr);
+    digit_info(pl, sa, pl.SB[ND * T + k], width, wr);
     const uint64_t v = uint64_t(d[k]) + cin;
     d[k] = uint32_t(v & ((uint64_t(1) << width) - 1));
     cin = v >> width;
@@ -293,52 +345,49 @@ __device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t T, ui
   d[3] += uint32_t(cin);
 }
 
-// digits of the thread's two runs (i1 = t and 512 + t) of tile T  ->  work buffer (forward columns).
+// digits of the thread's R runs (i1 = 512 d1 + t) of tile T  ->  work buffer (forward columns).
 // sub: small constant to subtract at digit 0 of the whole number, in the field (LL's x^2 - 2).
+template <int R>
 __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T, uint32_t t, uint32_t lane, uint32_t wave,
-                                           const uint32_t (&dg)[2][8], uint32_t sub, uint64_t* __restrict__ Wout) {
+                                           const uint32_t (&dg)[R][16 / R], uint32_t sub, uint64_t* __restrict__ Wout) {
+  using S = ColShape<R>;
+  constexpr int C = S::C, LC = S::LC;
   P2 x[8];
 #pragma unroll
-  for (int d1 = 0; d1 < 2; ++d1) {
+  for (int d1 = 0; d1 < R; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
-    const uint32_t sa = pl.SA[i1], sa1 = pl.SA[1024 + i1];       // odd digits: exponent split SA[M1 + i1] + SB[2 i2]
-    const uint64_t tah = gf::half(pl.TA[i1]), tah1 = gf::half(pl.TA[1024 + i1]);
+    const uint32_t sa = pl.SA[i1], sa1 = pl.SA[S::M1 + i1];       // odd digits: exponent split SA[M1 + i1] + SB[2 i2]
+    const uint64_t tah = gf::half(pl.TA[i1]), tah1 = gf::half(pl.TA[S::M1 + i1]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < C; ++c) {
       uint32_t w0, w1; bool wr0, wr1;
-      const uint32_t sb = pl.SB[8 * T + 2 * c];
+      const uint32_t sb = pl.SB[2 * C * T + 2 * c];
       digit_info(pl, sa, sb, w0, wr0);
       digit_info(pl, sa1, sb, w1, wr1);
       // weight TA*TB, halved when the exponents wrap: the halving is moved onto TA (once per run) and
       // the un-wrapped digits are doubled instead (digits are < 2^21, the product stays a mul_u32)
       const uint64_t a0 = gf::mul_u32(tah, dg[d1][2 * c] << (wr0 ? 0 : 1)), a1 = gf::mul_u32(tah1, dg[d1][2 * c + 1] << (wr1 ? 0 : 1));
-      x[4 * d1 + c] = {a0, a1};
+      x[C * d1 + c] = {a0, a1};
     }
     if (sub != 0 && T == 0 && i1 == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));   // digit 0 has weight 1
   }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const P2 u = x[c], v = x[4 + c];
-    x[c] = {gf::add(u.a, v.a), gf::add(u.b, v.b)};
-    x[4 + c] = {gf::sub(u.a, v.a), gf::sub(u.b, v.b)};
-  }
-#define MI355_CALL(W) seam16_fwd_const<W>(x)
+#define MI355_CALL(W) stage_r_fwd_const<R, W>(x)
   MI355_SWITCH8(wave, MI355_CALL)
 #undef MI355_CALL
   uint64_t sw[8];   // seam twiddles, requested before the exchange that hides their latency
   {
-    const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
-    const uint64_t* __restrict__ tw = pl.S1r + b * 16 + k1;
+    const uint32_t k1 = (t & 7) >> LC, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S1r + b * (8 * R) + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[2 * k2];
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[R * k2];
   }
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false>(x);
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   // four-step twiddle ingredients for the last stage (thread (k3|k1|k2|c)), requested two exchanges early
-  const uint32_t fc = t & 3, fkb = ((t >> 5) & 1) + 2 * ((t >> 2) & 7) + 16 * (t >> 6), fi2 = 4 * T + fc;
-  const uint64_t feA = (uint64_t(fi2) * fkb) % pl.m, feB = (uint64_t(fi2) * 128) % pl.m;
+  const uint32_t fc = t & (C - 1), fkb = ((t >> (3 + LC)) & (R - 1)) + R * ((t >> LC) & 7) + 8 * R * (t >> 6), fi2 = C * T + fc;
+  const uint64_t feA = (uint64_t(fi2) * fkb) % pl.m, feB = (uint64_t(fi2) * (64 * R)) % pl.m;
   const uint64_t fAl = pl.TWlo[feA & ((1u << pl.twh) - 1)], fAh = pl.TWhi[feA >> pl.twh];
   const uint64_t fBl = pl.TWlo[feB & ((1u << pl.twh) - 1)], fBh = pl.TWhi[feB >> pl.twh];
   const uint64_t fTB0 = pl.TB[2 * fi2];
@@ -346,8 +395,8 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   dft8p<false>(x);
   seam64<false>(x, wave);
   {
-    // lane = k1*32 + c*8 + k2  ->  slot offset k1*32 + k2*4 + c
-    const uint32_t off = (lane & 32) | ((lane & 7) << 2) | ((lane >> 3) & 3);
+    // lane = (k1 C + c) 8 + k2  ->  slot offset (k1 | k2 | c)
+    const uint32_t off = ((lane >> (3 + LC)) << (3 + LC)) | ((lane & 7) << LC) | ((lane >> 3) & (C - 1));
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) X[phys(wave * 512 + k * 64 + off)] = x[k];
@@ -361,7 +410,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
     const uint64_t A = gf::mul(fAl, fAh);
     const uint64_t B = gf::mul(fBl, fBh);
     uint64_t ca = gf::mul(A, fTB0);   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
-    const uint32_t row0 = __brev(kb) >> 22;   // bitrev10(kb): low 3 bits are zero
+    const uint32_t row0 = __brev(kb) >> (32 - S::LM);   // bitrev(kb): its low 3 bits are zero
     P2* W = reinterpret_cast<P2*>(Wout);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -372,23 +421,26 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   }
 }
 
-// work buffer -> digits of the thread's two runs of tile T (inverse columns, unweight, x a, carry).
+// work buffer -> digits of the thread's R runs of tile T (inverse columns, unweight, x a, carry).
 // scale: extra field factor (1, or M2 when the input is a front image rather than a middle output).
 // carry0[d1]: carry entering run d1 (strong: propagated through the whole run); cout[d1]: carry leaving it.
+template <int R>
 __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, uint32_t t, uint32_t lane, uint32_t wave,
                                           const uint64_t* __restrict__ Win, uint32_t a, uint64_t scale,
-                                          const uint64_t (&carry0)[2], uint32_t (&dg)[2][8], uint64_t (&cout)[2]) {
+                                          const uint64_t (&carry0)[R], uint32_t (&dg)[R][16 / R], uint64_t (&cout)[R]) {
+  using S = ColShape<R>;
+  constexpr int C = S::C, LC = S::LC;
   P2 x[8];
   {
-    const uint32_t c = t & 3, k2 = (t >> 2) & 7, k1 = (t >> 5) & 1, k3 = t >> 6;
-    const uint32_t kb = k1 + 2 * k2 + 16 * k3;
-    const uint32_t i2 = 4 * T + c;
-    const uint64_t ea = (uint64_t(i2) * kb) % pl.m, eb = (uint64_t(i2) * 128) % pl.m;
+    const uint32_t c = t & (C - 1), k2 = (t >> LC) & 7, k1 = (t >> (3 + LC)) & (R - 1), k3 = t >> 6;
+    const uint32_t kb = k1 + R * k2 + 8 * R * k3;
+    const uint32_t i2 = C * T + c;
+    const uint64_t ea = (uint64_t(i2) * kb) % pl.m, eb = (uint64_t(i2) * (64 * R)) % pl.m;
     uint64_t A = tw_lookup(pl, ea ? pl.m - ea : 0);
     const uint64_t B = tw_lookup(pl, eb ? pl.m - eb : 0);
     if (scale != 1) A = gf::mul(A, scale);
     uint64_t ca = gf::mul(A, pl.TBi[2 * i2]);   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
-    const uint32_t row0 = __brev(kb) >> 22;
+    const uint32_t row0 = __brev(kb) >> (32 - S::LM);
     const P2* W = reinterpret_cast<const P2*>(Win);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -403,7 +455,7 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   }
   dft8p<true>(x);
   {
-    const uint32_t off = (lane & 32) | ((lane & 7) << 2) | ((lane >> 3) & 3);
+    const uint32_t off = ((lane >> (3 + LC)) << (3 + LC)) | ((lane & 7) << LC) | ((lane >> 3) & (C - 1));
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) X[phys(j * 512 + t)] = x[j];
@@ -415,33 +467,39 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   dft8p<true>(x);
   uint64_t sw[8];
   {
-    const uint32_t k1 = (t >> 2) & 1, b = t >> 3;
-    const uint64_t* __restrict__ tw = pl.S1ri + b * 16 + k1;
+    const uint32_t k1 = (t & 7) >> LC, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S1ri + b * (8 * R) + k1;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[2 * k2];
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[R * k2];
   }
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   dft8p<true>(x);
-  // unweighting tables of the carry phase (thread (d2|d3|d4): runs i1 = t, 512 + t), requested one exchange early
-  const uint32_t bsa0 = pl.SA[t], bsa1 = pl.SA[512 + t], bsb0 = pl.SA[1024 + t], bsb1 = pl.SA[1536 + t];   // odd digits: second half
-  const uint64_t btai0 = pl.TAi[t], btai1 = pl.TAi[512 + t], btbi0 = pl.TAi[1024 + t], btbi1 = pl.TAi[1536 + t];
+  // unweighting tables of the carry phase (thread (d2|d3|d4): runs i1 = 512 d1 + t), requested one exchange early;
+  // odd digits take theirs from the second half of SA / TAi
+  uint32_t bsa_e[R], bsa_o[R];
+  uint64_t btai_e[R], btai_o[R];
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) {
+    bsa_e[d1] = pl.SA[512 * d1 + t]; bsa_o[d1] = pl.SA[S::M1 + 512 * d1 + t];
+    btai_e[d1] = pl.TAi[512 * d1 + t]; btai_o[d1] = pl.TAi[S::M1 + 512 * d1 + t];
+  }
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
-#define MI355_CALL(W) seam16_inv_butterfly_const<W>(x)
+#define MI355_CALL(W) stage_r_inv_const<R, W>(x)
   MI355_SWITCH8(wave, MI355_CALL)
 #undef MI355_CALL
 #pragma unroll
-  for (int d1 = 0; d1 < 2; ++d1) {
-    const uint32_t sa_e = d1 ? bsa1 : bsa0, sa_o = d1 ? bsb1 : bsb0;
-    const uint64_t tai_e = d1 ? btai1 : btai0, tai_o = d1 ? btbi1 : btbi0;
+  for (int d1 = 0; d1 < R; ++d1) {
+    const uint32_t sa_e = bsa_e[d1], sa_o = bsa_o[d1];
+    const uint64_t tai_e = btai_e[d1], tai_o = btai_o[d1];
     const uint64_t tai2_e = gf::dbl(tai_e), tai2_o = gf::dbl(tai_o);
     uint64_t carry = carry0[d1];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < S::ND; ++k) {
       uint32_t width; bool wrap;
-      digit_info(pl, (k & 1) ? sa_o : sa_e, pl.SB[8 * T + (k & ~1)], width, wrap);
-      const P2 v = x[4 * d1 + (k >> 1)];
+      digit_info(pl, (k & 1) ? sa_o : sa_e, pl.SB[S::ND * T + (k & ~1)], width, wrap);
+      const P2 v = x[C * d1 + (k >> 1)];
       const uint64_t u = (k & 1) ? gf::mul(v.b, wrap ? tai2_o : tai_o) : gf::mul(v.a, wrap ? tai2_e : tai_e);   // wrapped exponents: weight was halved
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
       if (a == 1) {               // the common case (uniform): no 64-bit multiplies
@@ -459,46 +517,60 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   }
 }
 
+// digit runs <-> registers: run (T, i1) is ND = 2C consecutive u32
+template <int R>
+__device__ __forceinline__ void load_run(const uint32_t* __restrict__ digits, uint32_t T, uint32_t i1, uint32_t (&d)[16 / R]) {
+  constexpr int Q = 4 / R;   // uint4 per run
+  const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * (512 * R) + i1) * Q;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { const uint4 v = src[q]; d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w; }
+}
+template <int R>
+__device__ __forceinline__ void store_run(uint32_t* __restrict__ digits, uint32_t T, uint32_t i1, const uint32_t (&d)[16 / R]) {
+  constexpr int Q = 4 / R;
+  uint4* dst = reinterpret_cast<uint4*>(digits) + (size_t(T) * (512 * R) + i1) * Q;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) dst[q] = make_uint4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+}
+
 // front sweep: digits (+ deferred run carries cbuf_in, nullable; + deferred subtraction) -> work buffer
-__global__ void __launch_bounds__(512, 4) k1_cols1024x4(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
-                                                        uint32_t sub, uint64_t* __restrict__ Wout) {
+template <int R>
+__global__ void __launch_bounds__(512, 4) k1_cols(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
+                                                  uint32_t sub, uint64_t* __restrict__ Wout) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
-  uint32_t dg[2][8];
+  uint32_t dg[R][16 / R];
 #pragma unroll
-  for (int d1 = 0; d1 < 2; ++d1) {
+  for (int d1 = 0; d1 < R; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
-    const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * 1024 + i1) * 2;
-    const uint4 q0 = src[0], q1 = src[1];
-    dg[d1][0] = q0.x; dg[d1][1] = q0.y; dg[d1][2] = q0.z; dg[d1][3] = q0.w;
-    dg[d1][4] = q1.x; dg[d1][5] = q1.y; dg[d1][6] = q1.z; dg[d1][7] = q1.w;
-    if (cbuf_in) apply_carry_in(pl, T, i1, carry_in_of(pl, cbuf_in, T, i1), dg[d1]);
+    load_run<R>(digits, T, i1, dg[d1]);
+    if (cbuf_in) apply_carry_in<16 / R>(pl, T, i1, carry_in_of(pl, cbuf_in, T, i1), dg[d1]);
   }
-  front_tile(pl, X, T, t, lane, wave, dg, sub, Wout);
+  front_tile<R>(pl, X, T, t, lane, wave, dg, sub, Wout);
 }
 
 // back sweep: work buffer -> digits + one carry word per run
-__global__ void __launch_bounds__(512, 4) k3_cols1024x4(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
-                                                        uint64_t* __restrict__ cbuf, uint32_t a, uint64_t scale) {
+template <int R>
+__global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+                                                  uint64_t* __restrict__ cbuf, uint32_t a, uint64_t scale) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, blockIdx.x, gridDim.x);
-  uint32_t dg[2][8];
-  uint64_t cout[2];
-  const uint64_t zero[2] = {0, 0};
-  back_tile(pl, X, T, t, lane, wave, Win, a, scale, zero, dg, cout);
+  uint32_t dg[R][16 / R];
+  uint64_t cout[R], zero[R];
 #pragma unroll
-  for (int d1 = 0; d1 < 2; ++d1) {
+  for (int d1 = 0; d1 < R; ++d1) zero[d1] = 0;
+  back_tile<R>(pl, X, T, t, lane, wave, Win, a, scale, zero, dg, cout);
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
-    uint4* dst = reinterpret_cast<uint4*>(digits) + (size_t(T) * 1024 + i1) * 2;
-    dst[0] = make_uint4(dg[d1][0], dg[d1][1], dg[d1][2], dg[d1][3]);
-    dst[1] = make_uint4(dg[d1][4], dg[d1][5], dg[d1][6], dg[d1][7]);
-    cbuf[size_t(T) * 1024 + i1] = cout[d1];
+    store_run<R>(digits, T, i1, dg[d1]);
+    cbuf[size_t(T) * (512 * R) + i1] = cout[d1];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused back + front sweep (work buffer -> work buffer, in place): the residue never goes to memory
-// as digits between two squarings.  A work-group owns the neighbouring tiles A = 2b and B = 2b+1:
+// Fused back + front sweep (work buffer -> work buffer, in place), M1 = 1024 only: the residue never goes
+// to memory as digits between two squarings.  A work-group owns the neighbouring tiles A = 2b and B = 2b+1:
 //   back(A) [carry-in 0]  ->  back(B) [carry-in = A's carry-out, same runs, same threads]
 //   -> publish B's carry-out words (write-through stores, then one flag store per work-group)
 //   -> front(B)  ->  wait for the previous work-group's flag, fetch its carry words -> front(A).
@@ -519,7 +591,7 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
     const uint32_t T = (s == 1) ? 2 * b + 1 : 2 * b;
     if (s < 2) {
       uint64_t cout[2];
-      back_tile(pl, X, T, t, lane, wave, Wbuf, a, 1, co, dnew, cout);
+      back_tile<2>(pl, X, T, t, lane, wave, Wbuf, a, 1, co, dnew, cout);
       co[0] = cout[0]; co[1] = cout[1];
     }
     if (s == 0) {
@@ -556,10 +628,10 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
         const uint64_t cin = __hip_atomic_load(cw + size_t(pb) * 1024 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 8; ++k) dnew[d1][k] = dhold[d1][k];
-        apply_carry_in(pl, T, i1, cin, dnew[d1]);
+        apply_carry_in<8>(pl, T, i1, cin, dnew[d1]);
       }
     }
-    front_tile(pl, X, T, t, lane, wave, dnew, 0, Wbuf);
+    front_tile<2>(pl, X, T, t, lane, wave, dnew, 0, Wbuf);
   }
 }
 
@@ -568,21 +640,22 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
 // ------------------------------- launch wrappers ---------------------------------------------
 
 bool v2_rows_supported(const DevPlan& pl) { return pl.M2 == 4096; }
-bool v2_cols_supported(const DevPlan& pl) { return pl.M1 == 1024 && pl.r5 == 1 && pl.C == 4 && pl.M2 >= 8; }
-
-hipError_t v2_configure() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<0>), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k1_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k3_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes));
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k31_cols1024x4), hipFuncAttributeMaxDynamicSharedMemorySize, int(v2::kLdsBytes + 64));
+// columns: M1 = 512 R, R in {1, 2, 4}, with C = 8 / R pairs per run (one 4096-pair tile per work-group)
+bool v2_cols_supported(const DevPlan& pl) {
+  return pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048) && pl.M1 * pl.C == 4096 && pl.M2 >= pl.C * 2 && pl.S1r != nullptr;
 }
+
+#define MI355_SET_LDS(KERNEL, BYTES)                                                                                          \
+  { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, int(BYTES)); \
+    if (e_ != hipSuccess) return e_; }
+hipError_t v2_configure() {
+  MI355_SET_LDS(v2::k2_rows4096<0>, v2::kLdsBytes) MI355_SET_LDS(v2::k2_rows4096<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k2_rows4096<2>, v2::kLdsBytes)
+  MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
+  MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
+  MI355_SET_LDS(v2::k31_cols1024x4, v2::kLdsBytes + 64)
+  return hipSuccess;
+}
+#undef MI355_SET_LDS
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
   switch (mode) {   // one instantiation per mode: the squaring kernel carries no multiply / image code
     case 0: hipLaunchKernelGGL(v2::k2_rows4096<0>, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
@@ -592,11 +665,21 @@ hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
   return hipGetLastError();
 }
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
-  hipLaunchKernelGGL(v2::k1_cols1024x4, dim3(pl.M2 / 4), dim3(512), v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
+  const dim3 grid(pl.M2 / pl.C), block(512);
+  switch (pl.M1) {
+    case 512: hipLaunchKernelGGL(v2::k1_cols<1>, grid, block, v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W); break;
+    case 1024: hipLaunchKernelGGL(v2::k1_cols<2>, grid, block, v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W); break;
+    default: hipLaunchKernelGGL(v2::k1_cols<4>, grid, block, v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W); break;
+  }
   return hipGetLastError();
 }
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s) {
-  hipLaunchKernelGGL(v2::k3_cols1024x4, dim3(pl.M2 / 4), dim3(512), v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale);
+  const dim3 grid(pl.M2 / pl.C), block(512);
+  switch (pl.M1) {
+    case 512: hipLaunchKernelGGL(v2::k3_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
+    case 1024: hipLaunchKernelGGL(v2::k3_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
+    default: hipLaunchKernelGGL(v2::k3_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
+  }
   return hipGetLastError();
 }
 hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s) {

@@ -63,7 +63,7 @@ struct Plan {
   std::vector<uint64_t> TWlo, TWhi;      // two-level omega_m table
   std::vector<uint64_t> UT1, UT2;        // omega_M1^e (e < M1), omega_M2^e (e < M2)
   // seam twiddles of the radix-8 kernels, laid out [b][ka] so that a wave reads runs of consecutive entries:
-  // S2r[b*64+ka] = omega_4096^(ka*b) (rows of 4096 = 64 x 64), S1r[b*16+ka] = omega_1024^(ka*b) (columns 16 x 64); *i = inverses
+  // S2r[b*64+ka] = omega_4096^(ka*b) (rows of 4096 = 64 x 64), S1r[b*(M1/64)+ka] = omega_M1^(ka*b) (columns M1 = 512/1024/2048 = (M1/64) x 64); *i = inverses
   std::vector<uint64_t> S2r, S2ri, S1r, S1ri;
   uint64_t I4 = 0, I4inv = 0;            // omega_4, omega_4^-1 (forward root convention)
   uint64_t W5[5] = {1, 0, 0, 0, 0}, W5i[5] = {1, 0, 0, 0, 0};
@@ -144,7 +144,8 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   // grow to 8192 pairs (128 KiB) when that is what C >= 4 needs
   uint32_t C = 1;
   while (C * 2 <= pl.M2 && size_t(pl.M1) * (C * 2) <= 4096 && C < 16) C *= 2;
-  while (C < 4 && C * 2 <= pl.M2 && size_t(pl.M1) * (C * 2) <= 8192) C *= 2;
+  // (not for columns of 2048: the register-resident column kernels take them as 4096-pair tiles with C = 2)
+  while (C < 4 && C * 2 <= pl.M2 && size_t(pl.M1) * (C * 2) <= 8192 && !(pl.r5 == 1 && pl.M1 == 2048)) C *= 2;
   while (C > 4 && pl.M2 / C < 256) C /= 2;   // mid-size transforms: enough tiles to fill 256 CUs
   if (want_c > 0) {
     C = uint32_t(want_c);
@@ -196,11 +197,12 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
       pl.S2r[b * 64 + ka] = pl.UT2[e]; pl.S2ri[b * 64 + ka] = pl.UT2[(4096 - e) & 4095];
     }
   }
-  if (pl.M1 == 1024) {
-    pl.S1r.resize(1024); pl.S1ri.resize(1024);
-    for (uint32_t b = 0; b < 64; ++b) for (uint32_t ka = 0; ka < 16; ++ka) {
+  if (pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048)) {   // M1 = 512 R = (8R) x 64
+    const uint32_t ka_n = pl.M1 / 64;
+    pl.S1r.resize(pl.M1); pl.S1ri.resize(pl.M1);
+    for (uint32_t b = 0; b < 64; ++b) for (uint32_t ka = 0; ka < ka_n; ++ka) {
       const uint32_t e = ka * b;
-      pl.S1r[b * 16 + ka] = pl.UT1[e]; pl.S1ri[b * 16 + ka] = pl.UT1[(1024 - e) & 1023];
+      pl.S1r[b * ka_n + ka] = pl.UT1[e]; pl.S1ri[b * ka_n + ka] = pl.UT1[(pl.M1 - e) & (pl.M1 - 1)];
     }
   }
   if (m % 4 == 0) { pl.I4 = gf::pow(om, m / 4); pl.I4inv = gf::inv(pl.I4); }

@@ -29,8 +29,9 @@ SMALL_CASES = [
     (933, None), (933, "m2=2,c=2"), (1801, "m2=8,c=4"), (1801, "m2=4,c=4"), (3997, "m2=16,c=4"), (3997, None),
     (9941, None), (9941, "m2=16,c=4"), (9941, "m2=64,c=8"), (9941, "m2=4,c=4"), (9941, "m2=128,c=2"),
     (13967, None), (13967, "m2=16,c=8"), (44497, None), (44497, "m2=32,c=4"), (102701, None), (102701, "m2=64,c=2"),
-    # shapes served by the register-resident radix-8 kernels: rows of 4096, columns of 1024 x 4
-    (300007, "m2=4096"), (300007, "m2=8,c=4"), (216091, None),
+    # shapes served by the register-resident radix-8 kernels: rows of 4096, columns of 512 x 8, 1024 x 4, 2048 x 2
+    (300007, "m2=4096"), (300007, "m2=8,c=4"), (300007, "m2=16,c=8"), (300007, "m2=4,c=2"), (216091, None),
+    (600011, "m2=32,c=8"), (600011, "m2=8,c=2"), (1200007, "m2=64,c=8"),
 ]
 
 
@@ -330,6 +331,36 @@ def test_unsupported_transform_size_is_refused():
     """n > 5*2^23 needs a third transform level this round does not have: creation fails loudly."""
     with pytest.raises(Exception, match="not supported"):
         Engine(800000011, 2)
+
+
+@pytest.mark.parametrize("p,n,m1", [(57885161, 1 << 22, 512), (250000013, 1 << 24, 2048)])
+def test_register_resident_columns_other_shapes_full_size(p, n, m1):
+    """n = 2^22 (columns of 512 x 8) and n = 2^24 (columns of 2048 x 2), both with rows of 4096: squarings with
+    a factor, the LL step, mul and add against the oracle's digit vectors, then an operation sequence that
+    exercises the deferred run carries (copy / set_multiplicand of a register with pending carries)."""
+    from prmers_amd import resolve_plan
+    assert ":m1=%d:m2=4096:" % m1 in resolve_plan(p)
+    o = orc.Oracle(p, 4)
+    assert o.n == n
+    rng = np.random.default_rng(p)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 5) as e:
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        for a in (1, 1, 3):
+            e.square_mul(0, a); o.square_mul(0, a)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        for _ in range(2):
+            e.square_mul(0); e.sub(0, 2); o.square_mul(0); o.sub(0, 2)
+        e.copy(1, 0); o.copy(1, 0)
+        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)
+        e.square_mul(0); o.square_mul(0)
+        e.mul(0, 2, 5); o.mul(0, 2, 5)
+        e.add(0, 1); o.add(0, 1)
+        e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert np.array_equal(e.digits(1), o.digits(1))
+        assert e.res64(0) == o.res64(0)
 
 
 @pytest.mark.parametrize("p,plan", [(300007, "m2=8,c=4"), (136279841, None)])
