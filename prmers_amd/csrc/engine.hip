@@ -177,9 +177,11 @@ void Engine::normalize(size_t r) {
 void Engine::run_front(size_t r) {
   if (v2cols_) {
     HIPCHK(v2_launch_front(dp_, digits(r), pending_carry_[r] ? cbuf(r) : nullptr, pending_sub_[r], work(), stream_));
+  } else if (pl_.C >= 2 && kind_[r] == kDigits && !pending_sub_[r]) {
+    HIPCHK(launch_front(dp_, digits(r), pending_carry_[r] ? cbuf(r) : nullptr, work(), stream_));   // does not modify digits(r)
   } else {
     normalize(r);
-    HIPCHK(launch_front(dp_, digits(r), work(), stream_));
+    HIPCHK(launch_front(dp_, digits(r), nullptr, work(), stream_));
   }
 }
 
@@ -196,8 +198,8 @@ void Engine::run_back(size_t r, uint32_t a) {
     pending_carry_[r] = 1;
   } else {
     HIPCHK(launch_back(dp_, work(), digits(r), cbuf(r), a, stream_));
-    HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_));
-    pending_carry_[r] = 0;
+    if (pl_.C >= 2) pending_carry_[r] = 1;   // the generic front folds the run carries in as well
+    else { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }
   }
   pending_sub_[r] = 0;
 }
@@ -389,9 +391,9 @@ void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
   } else {
     HIPCHK(launch_back(dp_, work(), digits(r), cbuf(r), a, stream_));
     if (ev) HIPCHK(hipEventRecord(ev[3], stream_));
-    HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_));
+    if (pl_.C >= 2) pending_carry_[r] = 1;
+    else { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }
     if (ev) HIPCHK(hipEventRecord(ev[4], stream_));
-    pending_carry_[r] = 0;
   }
   pending_sub_[r] = 0;
 }

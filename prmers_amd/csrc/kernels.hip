@@ -147,10 +147,19 @@ __device__ __forceinline__ void lds_radix5(const DevPlan& pl, P2* X, uint32_t nc
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
+// previous run (in digit order) of run (T, i1): same row, previous tile; first tile wraps to the
+// last tile of the previous row (cyclic: 2^p = 1)
+__device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_t* cbuf, uint32_t T, uint32_t i1) {
+  const uint32_t NT = pl.M2 / pl.C;
+  if (T > 0) return cbuf[size_t(T - 1) * pl.M1 + i1];
+  return cbuf[size_t(NT - 1) * pl.M1 + (i1 ? i1 - 1 : pl.M1 - 1)];
+}
+
 // ---------------------------------------------------------------------------------------------
 // front: one work-group per tile T (C adjacent columns, all M1 rows)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __restrict__ digits, uint64_t* __restrict__ Wout) {
+__global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
+                                                uint64_t* __restrict__ Wout) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
   const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
@@ -158,8 +167,28 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
 
   for (uint32_t e = tid; e < tile; e += nthr) {
     const uint32_t i1 = e / C, c = e - i1 * C, i2 = T * C + c;
-    const uint2 d = dg[e];
+    uint2 d = dg[e];
     const uint32_t sa = pl.SA[i1];
+    if (cbuf_in && c < 2) {
+      // deferred run carries (C >= 2): the carry word left by the previous run goes into the first digits
+      // of this one (three masked digits, the remainder onto the fourth: adc4, marin.cl:203-212).  The two
+      // threads that own the run's first two pairs each redo the four-digit chain and keep their pair.
+      uint64_t cin = carry_in_of(pl, cbuf_in, T, i1);
+      if (cin) {
+        const uint2 p0 = dg[i1 * C], p1 = dg[i1 * C + 1];
+        uint32_t dd[4] = {p0.x, p0.y, p1.x, p1.y};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          uint32_t width; bool wr;
+          digit_info(pl, sa, pl.SB[2 * (T * C) + k], width, wr);
+          const uint64_t v = uint64_t(dd[k]) + cin;
+          dd[k] = uint32_t(v & ((uint64_t(1) << width) - 1));
+          cin = v >> width;
+        }
+        dd[3] += uint32_t(cin);
+        d = c ? make_uint2(dd[2], dd[3]) : make_uint2(dd[0], dd[1]);
+      }
+    }
     const uint64_t ta = pl.TA[i1];
     uint32_t w0, w1; bool wr0, wr1;
     digit_info(pl, sa, pl.SB[2 * i2], w0, wr0);
@@ -278,13 +307,6 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
   }
 }
 
-// previous run (in digit order) of run (T, i1): same row, previous tile; first tile wraps to the
-// last tile of the previous row (cyclic: 2^p = 1)
-__device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_t* cbuf, uint32_t T, uint32_t i1) {
-  const uint32_t NT = pl.M2 / pl.C;
-  if (T > 0) return cbuf[size_t(T - 1) * pl.M1 + i1];
-  return cbuf[size_t(NT - 1) * pl.M1 + (i1 ? i1 - 1 : pl.M1 - 1)];
-}
 
 // carry fix: one thread per run; weak carry (the remainder, if any, stays on the run's last digit:
 // same contract as adc4, marin.cl:203-212)
@@ -372,9 +394,9 @@ static inline uint32_t block_for(size_t work) {
   return uint32_t(b);
 }
 
-hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, uint64_t* W, hipStream_t s) {
+hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint64_t* W, hipStream_t s) {
   const size_t tile = size_t(pl.M1) * pl.C;
-  hipLaunchKernelGGL(k_front, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, digits, W);
+  hipLaunchKernelGGL(k_front, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, digits, cbuf_in, W);
   return hipGetLastError();
 }
 hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {

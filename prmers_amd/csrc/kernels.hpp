@@ -17,7 +17,8 @@ struct DevPlan {
 };
 
 hipError_t configure_kernels(size_t lds_front, size_t lds_mid);
-hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, uint64_t* W, hipStream_t s);
+// cbuf_in (nullable, needs C >= 2): run carries left by the last back sweep, folded into the load
+hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint64_t* W, hipStream_t s);
 hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
 hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t* cbuf, hipStream_t s);

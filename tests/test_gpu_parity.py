@@ -37,9 +37,11 @@ SMALL_CASES = [
 
 @pytest.mark.parametrize("p,plan", SMALL_CASES)
 def test_prp_iterations_match_oracle_and_bigint(p, plan):
-    """x <- x^2 from 3: digit vector bit-exact vs the oracle each iteration, value vs Python ints."""
+    """x <- x^2 from 3: digit vector bit-exact vs the oracle each iteration, value vs Python ints
+    (Python big-integer squaring only up to p = 250000: beyond that it would dominate the suite)."""
     iters = min(p, 150)
     Mp = (1 << p) - 1
+    bigint = p <= 250000
     o = orc.Oracle(p, 2)
     with Engine(p, 2, plan=plan) as e:
         assert e.n == o.n
@@ -47,10 +49,12 @@ def test_prp_iterations_match_oracle_and_bigint(p, plan):
         x = 3
         for it in range(iters):
             e.square_mul(0); o.square_mul(0)
-            x = x * x % Mp
+            if bigint:
+                x = x * x % Mp
             if it % 7 == 0 or it > iters - 4:
                 assert np.array_equal(e.digits(0), o.digits(0)), (p, plan, it)
-                assert e.get_int(0) == x
+                if bigint:
+                    assert e.get_int(0) == x
         assert e.res64(0) == o.res64(0)
 
 
