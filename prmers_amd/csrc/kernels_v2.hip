@@ -10,8 +10,8 @@
 //   * only the seam between two blocks is a general GF(P) multiplication (one per element and
 //     direction, from a universal omega_M table), against three per radix-4 level pair in the
 //     reference's schedule (marin.cl:304-318: fwd4/bck4 with r1, r23.s0, r23.s1).
-// Shapes served: rows M2 = 4096 (8.8.8.8), columns M1 = 1024 with C = 4 (2.8.8.8).  Everything else
-// runs on the generic set.  Row order of the work buffer and digit layout are those of kernels.hip,
+// Shapes served: rows M2 = 4096 (8.8.8.8); columns M1 = 512 R (R.8.8.8, R = 1, 2, 4) with C = 8/R pairs per
+// run.  Everything else runs on the generic set.  Row order of the work buffer and digit layout are those of kernels.hip,
 // so the two sets interoperate kernel by kernel (the multiplicand image layout differs: an engine
 // uses one middle kernel for both set_multiplicand and mul).
 //
