@@ -27,6 +27,7 @@ struct alignas(16) P2 { uint64_t a, b; };
 __device__ __forceinline__ P2 p2_add(P2 x, P2 y) { return {gf::add(x.a, y.a), gf::add(x.b, y.b)}; }
 __device__ __forceinline__ P2 p2_sub(P2 x, P2 y) { return {gf::sub(x.a, y.a), gf::sub(x.b, y.b)}; }
 __device__ __forceinline__ P2 p2_mul(P2 x, uint64_t w) { return {gf::mul(x.a, w), gf::mul(x.b, w)}; }
+__device__ __forceinline__ P2 p2_shift48(P2 x) { return {gf::mul_pow2(x.a, 48), gf::mul_pow2(x.b, 48)}; }
 
 // omega_m^e from the two-level table (e < m)
 __device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
@@ -77,7 +78,7 @@ __device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, u
         P2 x0 = X[e0], x1 = X[e0 + es], x2 = X[e0 + 2 * es], x3 = X[e0 + 3 * es];
         if (!INVERSE) {
           const uint64_t w1 = root[r1], w2 = root[2 * r1], w3 = root[3 * r1];
-          const P2 a = p2_add(x0, x2), b = p2_add(x1, x3), c = p2_sub(x0, x2), d = p2_mul(p2_sub(x1, x3), I4);
+          const P2 a = p2_add(x0, x2), b = p2_add(x1, x3), c = p2_sub(x0, x2), d = p2_shift48(p2_sub(x1, x3));   // omega_4 = 2^48 (checked in make_plan)
           X[e0] = p2_add(a, b);
           X[e0 + es] = p2_mul(p2_sub(a, b), w2);
           X[e0 + 2 * es] = p2_mul(p2_add(c, d), w1);
@@ -88,7 +89,7 @@ __device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, u
           const P2 y1 = p2_mul(x1, w2);
           const P2 A = p2_add(x0, y1), B = p2_sub(x0, y1);
           const P2 y2 = p2_mul(x2, w1), y3 = p2_mul(x3, w3);
-          const P2 Cc = p2_add(y2, y3), D = p2_mul(p2_sub(y2, y3), I4);  // I4 = omega_4^-1 here
+          const P2 Cc = p2_add(y2, y3), D = p2_shift48(p2_sub(y3, y2));   // omega_4^-1 = -2^48
           X[e0] = p2_add(A, Cc);
           X[e0 + 2 * es] = p2_sub(A, Cc);
           X[e0 + es] = p2_add(B, D);
@@ -111,36 +112,46 @@ __device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, u
   }
 }
 
+// 5-point DFT, X[k] = sum_r x[r] w^(rk) with w = omega_5 (INVERSE: w^-1), 4 general multiplications:
+//   t1 = x1+x4, t2 = x2+x3, t3 = x1-x4, t4 = x2-x3, t5 = t1+t2;  X0 = x0 + t5
+//   A = x0 - t5/4 (1 + (w+w^4) + (w^2+w^3) = 0; -1/4 = 2^94);  B1,2 = A +- beta (t1 - t2), beta = ((w+w^4) - (w^2+w^3))/4
+//   P = k1 t3 + k2 t4, Q = k2 t3 - k1 t4 with k1 = (w-w^4)/2, k2 = (w^2-w^3)/2, from three products
+//   k1 (t3+t4), (k2-k1) t4, (k1+k2) t3;  X1,4 = B1 +- P, X2,3 = B2 +- Q (signs swapped for the inverse).
+// c5 = {beta, k1, k2-k1, k1+k2} (plan.hpp).
+template <bool INVERSE>
+__device__ __forceinline__ void dft5(P2 (&x)[5], const uint64_t (&c5)[4]) {
+  const P2 t1 = p2_add(x[1], x[4]), t2 = p2_add(x[2], x[3]), t3 = p2_sub(x[1], x[4]), t4 = p2_sub(x[2], x[3]);
+  const P2 t5 = p2_add(t1, t2);
+  const P2 A = p2_add(x[0], P2{gf::mul_pow2(t5.a, 94), gf::mul_pow2(t5.b, 94)});
+  const P2 m2 = p2_mul(p2_sub(t1, t2), c5[0]);
+  const P2 B1 = p2_add(A, m2), B2 = p2_sub(A, m2);
+  const P2 m3 = p2_mul(p2_add(t3, t4), c5[1]), m4 = p2_mul(t4, c5[2]), m5 = p2_mul(t3, c5[3]);
+  const P2 Pp = p2_add(m3, m4), Q = p2_sub(m5, m3);
+  x[0] = p2_add(x[0], t5);
+  if (!INVERSE) { x[1] = p2_add(B1, Pp); x[4] = p2_sub(B1, Pp); x[2] = p2_add(B2, Q); x[3] = p2_sub(B2, Q); }
+  else          { x[1] = p2_sub(B1, Pp); x[4] = p2_add(B1, Pp); x[2] = p2_sub(B2, Q); x[3] = p2_add(B2, Q); }
+}
+
 // radix-5 stage of the column DFT (first forward / last inverse): 5 blocks of L1, twiddle omega_M1^(t*k)
 template <bool INVERSE>
 __device__ __forceinline__ void lds_radix5(const DevPlan& pl, P2* X, uint32_t ncols, uint32_t tid, uint32_t nthr) {
   const uint32_t L1 = pl.L1, total = L1 * ncols;
   for (uint32_t idx = tid; idx < total; idx += nthr) {
     const uint32_t col = idx % ncols, t = idx / ncols;
-    P2 x[5], y[5];
+    P2 x[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) x[r] = X[(L1 * r + t) * ncols + col];
     if (!INVERSE) {
+      dft5<false>(x, pl.W5c);
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        P2 s = x[0];
-#pragma unroll
-        for (int r = 1; r < 5; ++r) s = p2_add(s, p2_mul(x[r], pl.W5[(r * k) % 5]));
-        y[k] = (k == 0) ? s : p2_mul(s, pl.UT1[t * k]);  // t*k < M1
-      }
+      for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[t * k]);  // t*k < M1
     } else {
 #pragma unroll
       for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[(t * k) ? pl.M1 - t * k : 0]);
-#pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        P2 s = x[0];
-#pragma unroll
-        for (int k = 1; k < 5; ++k) s = p2_add(s, p2_mul(x[k], pl.W5i[(r * k) % 5]));
-        y[r] = s;
-      }
+      dft5<true>(x, pl.W5c);
     }
 #pragma unroll
-    for (int r = 0; r < 5; ++r) X[(L1 * r + t) * ncols + col] = y[r];
+    for (int r = 0; r < 5; ++r) X[(L1 * r + t) * ncols + col] = x[r];
   }
   __syncthreads();
 }

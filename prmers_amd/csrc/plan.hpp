@@ -67,6 +67,7 @@ struct Plan {
   std::vector<uint64_t> S2r, S2ri, S1r, S1ri;
   uint64_t I4 = 0, I4inv = 0;            // omega_4, omega_4^-1 (forward root convention)
   uint64_t W5[5] = {1, 0, 0, 0, 0}, W5i[5] = {1, 0, 0, 0, 0};
+  uint64_t W5c[4] = {0, 0, 0, 0};        // 5-point DFT constants {beta, k1, k2-k1, k1+k2} (kernels.hip dft5)
 
   size_t tiles() const { return M2 / C; }
   size_t runs() const { return tiles() * M1; }
@@ -207,9 +208,13 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   }
   if (m % 4 == 0) { pl.I4 = gf::pow(om, m / 4); pl.I4inv = gf::inv(pl.I4); }
   else { pl.I4 = gf::root_of_unity(4); pl.I4inv = gf::inv(pl.I4); }
+  if (pl.I4 != (uint64_t(1) << 48)) throw std::runtime_error("internal: omega_4 is expected to be 2^48");   // the kernels shift instead of multiplying
   if (pl.r5 == 5) {
     const uint64_t w5 = gf::pow(om, m / 5);
     for (int i = 0; i < 5; ++i) { pl.W5[i] = gf::pow(w5, uint64_t(i)); pl.W5i[i] = gf::inv(pl.W5[i]); }
+    const uint64_t a = gf::add(pl.W5[1], pl.W5[4]), b = gf::add(pl.W5[2], pl.W5[3]);
+    const uint64_t k1 = gf::half(gf::sub(pl.W5[1], pl.W5[4])), k2 = gf::half(gf::sub(pl.W5[2], pl.W5[3]));
+    pl.W5c[0] = gf::half(gf::half(gf::sub(a, b))); pl.W5c[1] = k1; pl.W5c[2] = gf::sub(k2, k1); pl.W5c[3] = gf::add(k1, k2);
   }
   return pl;
 }
