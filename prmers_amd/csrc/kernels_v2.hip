@@ -10,7 +10,7 @@
 //   * only the seam between two blocks is a general GF(P) multiplication (one per element and
 //     direction, from a universal omega_M table), against three per radix-4 level pair in the
 //     reference's schedule (marin.cl:304-318: fwd4/bck4 with r1, r23.s0, r23.s1).
-// Shapes served: rows M2 = 4096 (8.8.8.8); columns M1 = 512 R (R.8.8.8, R = 1, 2, 4) with C = 8/R pairs per
+// Shapes served: rows M2 = 4096 (8.8.8.8) and 8192 (2 x 4096 under one radix-2 level); columns M1 = 512 R (R.8.8.8, R = 1, 2, 4) with C = 8/R pairs per
 // run.  Everything else runs on the generic set.  Row order of the work buffer and digit layout are those of kernels.hip,
 // so the two sets interoperate kernel by kernel (the multiplicand image layout differs: an engine
 // uses one middle kernel for both set_multiplicand and mul).
@@ -132,27 +132,43 @@ __device__ __forceinline__ uint32_t tile_of_block(const DevPlan& pl, uint32_t b,
 // pointwise in registers, then the mirror image back to natural order.
 // mode 0: square, 1: multiply by image Y, 2: forward only (writes the image).
 // ---------------------------------------------------------------------------------------------
-template <int mode>
-__global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
-                                                      uint64_t* __restrict__ Wout, uint32_t sub) {
-  P2* X = reinterpret_cast<P2*>(smem_v2);
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), row = blockIdx.x;
-  const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 4096;
-  P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * 4096;
+// H = 2 serves rows of 8192 with 1024 threads: one radix-2 level on top (element i and i + 4096; thread group
+// h = 0 forms the sums, h = 1 the differences times omega_8192^i, each group loads both halves), then each
+// group runs the 4096-point machinery on its own LDS half (2 x 72 KiB); output index k of group h is row
+// frequency 2k + h.  The inverse ends with the mirror butterfly through LDS.
+template <int mode, int H>
+__global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
+                                                          uint64_t* __restrict__ Wout, uint32_t sub) {
+  const uint32_t h = (H == 2) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0u;
+  P2* X = reinterpret_cast<P2*>(smem_v2) + h * kLdsSlots;
+  const uint32_t t = threadIdx.x & 511, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7), row = blockIdx.x;
+  const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * (4096 * H);
+  P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * (4096 * H) + h * 4096;
   P2 x[8];
   // table words of the pointwise stage, requested first: their latency hides behind the forward transform
   const uint32_t kb = (lane >> 3) + 8 * (lane & 7) + 64 * wave;   // S4 thread (k3|k1|k2): frequency base k1 + 8 k2 + 64 k3
   const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;       // column-DFT slot -> frequency (kernels.hip freq1)
   const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
-  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * kb;
+  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * (H * kb + h);   // row frequency of X[kb]: H kb + h
   const uint64_t rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)], rho_hi = pl.TWhi[erho >> pl.twh];
 
   // ---- forward ----
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = in[512 * j + t];
   // deferred small subtraction (LL's -2) on a front image: digit 0 has weight 1 and reaches column 0,
   // plane a of every row unchanged
-  if (sub != 0 && t == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));
+  if (H == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = in[512 * j + t];
+    if (sub != 0 && t == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      P2 lo = in[512 * j + t];
+      const P2 hi = in[4096 + 512 * j + t];
+      if (j == 0 && sub != 0 && t == 0) lo.a = gf::sub(lo.a, uint64_t(sub));
+      if (h == 0) x[j] = {gf::add(lo.a, hi.a), gf::add(lo.b, hi.b)};
+      else x[j] = p2_mul(P2{gf::sub(lo.a, hi.a), gf::sub(lo.b, hi.b)}, pl.UT2[512 * j + t]);
+    }
+  }
   dft8p<false>(x);
   seam64<false>(x, wave);
   uint64_t sw[8];   // seam twiddles: loaded before the exchange so that their latency hides behind it
@@ -186,7 +202,7 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   // ---- pointwise: reg k4 holds X[kb + 512 k4]; rho = omega_m^(k1row + M1 k) = rho0 * omega_8^k4 ----
   {
     const uint64_t rho0 = gf::mul(rho_lo, rho_hi);
-    const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * 4096;
+    const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * (4096 * H) + h * 4096;
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       // omega_8^k4 = 2^(120 k4): +1, -2^24, +2^48, -2^72, -1, +2^24, -2^48, +2^72
@@ -233,6 +249,22 @@ __global__ void __launch_bounds__(512, 4) k2_rows4096(DevPlan pl, const uint64_t
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
   seam64<true>(x, wave);
   dft8p<true>(x);
+  if (H == 2) {   // mirror of the top radix-2 level: lo = A + B w^-i, hi = A - B w^-i (A from group 0, B from group 1)
+    if (h == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const uint32_t i = 512 * j + t; x[j] = p2_mul(x[j], pl.UT2[i ? 8192 - i : 0]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) X[phys(j * 512 + t)] = x[j];
+    __syncthreads();
+    const P2* Xo = reinterpret_cast<const P2*>(smem_v2) + (1 - h) * kLdsSlots;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const P2 o = Xo[phys(j * 512 + t)];
+      x[j] = (h == 0) ? P2{gf::add(x[j].a, o.a), gf::add(x[j].b, o.b)} : P2{gf::sub(o.a, x[j].a), gf::sub(o.b, x[j].b)};
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
 }
@@ -639,7 +671,7 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
 
 // ------------------------------- launch wrappers ---------------------------------------------
 
-bool v2_rows_supported(const DevPlan& pl) { return pl.M2 == 4096; }
+bool v2_rows_supported(const DevPlan& pl) { return (pl.M2 == 4096 || pl.M2 == 8192) && pl.S2r != nullptr; }
 // columns: M1 = 512 R, R in {1, 2, 4}, with C = 8 / R pairs per run (one 4096-pair tile per work-group)
 bool v2_cols_supported(const DevPlan& pl) {
   return pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048) && pl.M1 * pl.C == 4096 && pl.M2 >= pl.C * 2 && pl.S1r != nullptr;
@@ -649,7 +681,8 @@ bool v2_cols_supported(const DevPlan& pl) {
   { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, int(BYTES)); \
     if (e_ != hipSuccess) return e_; }
 hipError_t v2_configure() {
-  MI355_SET_LDS(v2::k2_rows4096<0>, v2::kLdsBytes) MI355_SET_LDS(v2::k2_rows4096<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k2_rows4096<2>, v2::kLdsBytes)
+  MI355_SET_LDS((v2::k2_rows4096<0, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 1>), v2::kLdsBytes)
+  MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes)
   MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k31_cols1024x4, v2::kLdsBytes + 64)
@@ -657,11 +690,13 @@ hipError_t v2_configure() {
 }
 #undef MI355_SET_LDS
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
-  switch (mode) {   // one instantiation per mode: the squaring kernel carries no multiply / image code
-    case 0: hipLaunchKernelGGL(v2::k2_rows4096<0>, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
-    case 1: hipLaunchKernelGGL(v2::k2_rows4096<1>, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
-    default: hipLaunchKernelGGL(v2::k2_rows4096<2>, dim3(pl.M1), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
+#define MI355_ROWS(MODE, HH) hipLaunchKernelGGL((v2::k2_rows4096<MODE, HH>), dim3(pl.M1), dim3(512 * HH), HH * v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
+  if (pl.M2 == 4096) {   // one instantiation per mode: the squaring kernel carries no multiply / image code
+    switch (mode) { case 0: MI355_ROWS(0, 1); break; case 1: MI355_ROWS(1, 1); break; default: MI355_ROWS(2, 1); break; }
+  } else {
+    switch (mode) { case 0: MI355_ROWS(0, 2); break; case 1: MI355_ROWS(1, 2); break; default: MI355_ROWS(2, 2); break; }
   }
+#undef MI355_ROWS
   return hipGetLastError();
 }
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {

@@ -191,11 +191,12 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   const uint64_t om1 = gf::pow(om, pl.M2), om2 = gf::pow(om, pl.M1);
   pl.UT1.resize(pl.M1); pl.UT1[0] = 1; for (uint32_t i = 1; i < pl.M1; ++i) pl.UT1[i] = gf::mul(pl.UT1[i - 1], om1);
   pl.UT2.resize(pl.M2); pl.UT2[0] = 1; for (uint32_t i = 1; i < pl.M2; ++i) pl.UT2[i] = gf::mul(pl.UT2[i - 1], om2);
-  if (pl.M2 == 4096) {
+  if (pl.M2 == 4096 || pl.M2 == 8192) {   // rows of 8192 = one radix-2 level over two 4096-point transforms
+    const uint32_t st = pl.M2 / 4096;       // omega_4096 = omega_M2^st
     pl.S2r.resize(4096); pl.S2ri.resize(4096);
     for (uint32_t b = 0; b < 64; ++b) for (uint32_t ka = 0; ka < 64; ++ka) {
       const uint32_t e = ka * b;
-      pl.S2r[b * 64 + ka] = pl.UT2[e]; pl.S2ri[b * 64 + ka] = pl.UT2[(4096 - e) & 4095];
+      pl.S2r[b * 64 + ka] = pl.UT2[st * e]; pl.S2ri[b * 64 + ka] = pl.UT2[st * ((4096 - e) & 4095)];
     }
   }
   if (pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048)) {   // M1 = 512 R = (8R) x 64
