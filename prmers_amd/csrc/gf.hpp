@@ -133,7 +133,14 @@ GF_HD uint64_t mul_pow2(uint64_t a, unsigned s) {
     const uint64_t l1 = lo2 >> 32, l0 = lo2 & 0xffffffffull;
     r = sub((l0 << 32) - l0, l1 + (hi2 << 32));
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // On the device a negated zero is left as P (two instructions instead of five).  P behaves as zero in
+  // add / sub / mul / mul_pow2 (their bounds hold for any operand <= P) and every kernel ends its chain
+  // with a multiplication, whose result is canonical again, before anything is compared or split into digits.
+  return negate ? P - r : r;
+#else
   return negate ? neg(r) : r;
+#endif
 }
 
 // sqrt(-1) = 2^48
