@@ -27,6 +27,17 @@ GF_HD uint64_t add(uint64_t a, uint64_t b) {
   return s + (ge ? EPS : 0ull);
 }
 
+// a + b without the final ">= P" fold: the result is congruent to a + b but may lie anywhere in [0, 2^64).
+// For operands <= P the single carry fold cannot overflow again (a + b - 2^64 + EPS < 2^64).  Only for
+// values whose next use is a multiplication (mul, mul_u32, mul_pow2 accept any 64-bit operand).
+GF_HD uint64_t add_lazy(uint64_t a, uint64_t b) {
+  uint64_t s = a + b;
+  return s + ((s < a) ? EPS : 0ull);
+}
+
+// any 64-bit representative -> [0, P)
+GF_HD uint64_t fold(uint64_t a) { return a + ((a >= P) ? EPS : 0ull); }
+
 GF_HD uint64_t sub(uint64_t a, uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // the borrow comes out of the 32-bit subtract-with-borrow pair itself (one 64-bit compare less than

@@ -12,7 +12,9 @@ constexpr unsigned shift64(unsigned e) { return (LOG2_W64 * e) % 192; }   // ome
 // out[k] = sum_j in[j] * W^(jk), W = omega_8 (forward) or omega_8^-1 (INV, unnormalised), in place.
 // Signs of W^1 = -2^24, W^3 = -2^72 (forward) and W^-2 = -2^48 (inverse) are folded into the order
 // of the subtractions.
-template <bool INV>
+// LAZY: outputs that may be left un-folded (add_lazy) because the caller multiplies them next:
+// 0 none, 1 outputs 1..3, 2 outputs 0..3 (outputs 4..7 are differences and canonical anyway).
+template <bool INV, int LAZY = 0>
 GF_HD void dft8(uint64_t (&x)[8]) {
   const uint64_t a0 = add(x[0], x[4]), a1 = add(x[1], x[5]), a2 = add(x[2], x[6]), a3 = add(x[3], x[7]);
   uint64_t b0 = sub(x[0], x[4]), b1, b2, b3;
@@ -29,10 +31,10 @@ GF_HD void dft8(uint64_t (&x)[8]) {
   const uint64_t d1 = mul_pow2(INV ? sub(a3, a1) : sub(a1, a3), 48);
   const uint64_t e0 = add(b0, b2), e1 = add(b1, b3), f0 = sub(b0, b2);
   const uint64_t f1 = mul_pow2(INV ? sub(b3, b1) : sub(b1, b3), 48);
-  x[0] = add(c0, c1); x[4] = sub(c0, c1);
-  x[2] = add(d0, d1); x[6] = sub(d0, d1);
-  x[1] = add(e0, e1); x[5] = sub(e0, e1);
-  x[3] = add(f0, f1); x[7] = sub(f0, f1);
+  x[0] = (LAZY >= 2) ? add_lazy(c0, c1) : add(c0, c1); x[4] = sub(c0, c1);
+  x[2] = (LAZY >= 1) ? add_lazy(d0, d1) : add(d0, d1); x[6] = sub(d0, d1);
+  x[1] = (LAZY >= 1) ? add_lazy(e0, e1) : add(e0, e1); x[5] = sub(e0, e1);
+  x[3] = (LAZY >= 1) ? add_lazy(f0, f1) : add(f0, f1); x[7] = sub(f0, f1);
 }
 
 }  // namespace gf

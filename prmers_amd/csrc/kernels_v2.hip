@@ -36,13 +36,13 @@ constexpr uint32_t kLdsBytes = kLdsSlots * 16;
 
 __device__ __forceinline__ P2 p2_mul(P2 x, uint64_t w) { return {gf::mul(x.a, w), gf::mul(x.b, w)}; }
 
-template <bool INV>
+template <bool INV, int LAZY = 0>
 __device__ __forceinline__ void dft8p(P2 (&x)[8]) {
   uint64_t u[8], v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { u[j] = x[j].a; v[j] = x[j].b; }
-  gf::dft8<INV>(u);
-  gf::dft8<INV>(v);
+  gf::dft8<INV, LAZY>(u);
+  gf::dft8<INV, LAZY>(v);
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = {u[j], v[j]};
 }
@@ -62,10 +62,17 @@ __device__ __forceinline__ void seam64_const(P2 (&x)[8]) {
     x[k] = {gf::mul_pow2(x[k].a, s), gf::mul_pow2(x[k].b, s)};
   }
 }
-template <bool INV>
+// FOLD0: the caller left x[1..3] un-folded (dft8 LAZY = 1) because the shifts below accept any operand; wave 0
+// shifts by nothing, so it folds them here instead.
+template <bool INV, bool FOLD0 = false>
 __device__ __forceinline__ void seam64(P2 (&x)[8], uint32_t wave) {
   switch (wave) {
-    case 0: break;
+    case 0:
+      if (FOLD0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) x[k] = {gf::fold(x[k].a), gf::fold(x[k].b)};
+      }
+      break;
     case 1: seam64_const<1, INV>(x); break;
     case 2: seam64_const<2, INV>(x); break;
     case 3: seam64_const<3, INV>(x); break;
@@ -169,8 +176,8 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
       else x[j] = p2_mul(P2{gf::sub(lo.a, hi.a), gf::sub(lo.b, hi.b)}, pl.UT2[512 * j + t]);
     }
   }
-  dft8p<false>(x);
-  seam64<false>(x, wave);
+  dft8p<false, 1>(x);   // outputs 1..7 are shifted next, output 0 is not
+  seam64<false, true>(x, wave);
   uint64_t sw[8];   // seam twiddles: loaded before the exchange so that their latency hides behind it
   {
     const uint32_t k1 = t & 7, b = t >> 3;
@@ -179,19 +186,19 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
     for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[8 * k2];
   }
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
-  dft8p<false>(x);
+  dft8p<false, 2>(x);   // all outputs are multiplied next
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
-  dft8p<false>(x);
-  seam64<false>(x, wave);
+  dft8p<false, 1>(x);
+  seam64<false, true>(x, wave);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 8; ++k) X[phys(wave * 512 + k * 64 + lane)] = x[k];
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = X[phys(j * 512 + t)];
-  dft8p<false>(x);
+  dft8p<false, 2>(x);   // mode 2 stores them for a later multiplication, the pointwise stage multiplies
 
   if (mode == 2) {
 #pragma unroll
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
         const uint64_t q = gf::mul_pow2(gf::mul(gf::sqr(u.b), rho0), sh);
         const uint64_t s0 = gf::sqr(u.a);
         r.a = neg ? gf::sub(s0, q) : gf::add(s0, q);
-        r.b = gf::mul(u.b, gf::dbl(u.a));
+        r.b = gf::dbl(gf::mul(u.b, u.a));   // (u.a may be an un-folded sum: double the product, not the operand)
       } else {           // marin.cl:387-392
         const P2 y = Y[512 * k4 + t];
         const uint64_t q = gf::mul_pow2(gf::mul(gf::mul(u.b, y.b), rho0), sh);
@@ -235,7 +242,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
 #pragma unroll
   for (int k = 0; k < 8; ++k) x[k] = X[phys(wave * 512 + k * 64 + lane)];
   seam64<true>(x, wave);
-  dft8p<true>(x);
+  dft8p<true, 2>(x);   // exchanged, then multiplied by the seam twiddles
   {
     const uint32_t k1 = t & 7, b = t >> 3;
     const uint64_t* __restrict__ tw = pl.S2ri + b * 64 + k1;
@@ -248,7 +255,8 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   dft8p<true>(x);
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
   seam64<true>(x, wave);
-  dft8p<true>(x);
+  if (H == 1) dft8p<true, 2>(x);   // stored for a back sweep, which multiplies by its twiddle first
+  else dft8p<true>(x);
   if (H == 2) {   // mirror of the top radix-2 level: lo = A + B w^-i, hi = A - B w^-i (A from group 0, B from group 1)
     if (h == 1) {
 #pragma unroll
@@ -414,7 +422,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
     for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[R * k2];
   }
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
-  dft8p<false>(x);
+  dft8p<false, 2>(x);
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   // four-step twiddle ingredients for the last stage (thread (k3|k1|k2|c)), requested two exchanges early
@@ -424,8 +432,8 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   const uint64_t fBl = pl.TWlo[feB & ((1u << pl.twh) - 1)], fBh = pl.TWhi[feB >> pl.twh];
   const uint64_t fTB0 = pl.TB[2 * fi2];
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
-  dft8p<false>(x);
-  seam64<false>(x, wave);
+  dft8p<false, 1>(x);
+  seam64<false, true>(x, wave);
   {
     // lane = (k1 C + c) 8 + k2  ->  slot offset (k1 | k2 | c)
     const uint32_t off = ((lane >> (3 + LC)) << (3 + LC)) | ((lane & 7) << LC) | ((lane >> 3) & (C - 1));
@@ -436,7 +444,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = X[phys(j * 512 + t)];
   }
-  dft8p<false>(x);
+  dft8p<false, 2>(x);   // four-step twiddle next
   {
     const uint32_t kb = fkb, i2 = fi2;
     const uint64_t A = gf::mul(fAl, fAh);
@@ -496,7 +504,7 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
     for (int k = 0; k < 8; ++k) x[k] = X[phys(wave * 512 + k * 64 + off)];
   }
   seam64<true>(x, wave);
-  dft8p<true>(x);
+  dft8p<true, 2>(x);
   uint64_t sw[8];
   {
     const uint32_t k1 = (t & 7) >> LC, b = t >> 3;
