@@ -75,6 +75,12 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   dp_.M1 = pl_.M1; dp_.M2 = pl_.M2; dp_.L1 = pl_.L1; dp_.logL1 = pl_.logL1; dp_.logM2 = pl_.logM2;
   dp_.r5 = pl_.r5; dp_.C = pl_.C; dp_.q = pl_.q; dp_.t = pl_.t; dp_.twh = pl_.twh;
   dp_.I4 = pl_.I4; dp_.I4inv = pl_.I4inv;
+  dp_.DI = nullptr;
+  if (!pl_.DI.empty()) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&di_), pl_.DI.size() * 4));
+    HIPCHK(hipMemcpy(di_, pl_.DI.data(), pl_.DI.size() * 4, hipMemcpyHostToDevice));
+    dp_.DI = di_;
+  }
   for (int i = 0; i < 4; ++i) dp_.W5c[i] = pl_.W5c[i];
   { const char* tn = std::getenv("MI355_TUNE"); dp_.tune = tn ? uint32_t(std::atoi(tn)) : 0u; }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
@@ -118,6 +124,7 @@ Engine::~Engine() {
   if (flags_) (void)hipFree(flags_);
   if (cbuf_) (void)hipFree(cbuf_);
   if (tables_) (void)hipFree(tables_);
+  if (di_) (void)hipFree(di_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 

@@ -92,6 +92,7 @@ class Engine {
   bool fused_ = false;
   uint64_t* cbuf_ = nullptr;
   void* tables_ = nullptr;
+  uint32_t* di_ = nullptr;   // digit-info words of the register-resident column kernels (plan.hpp DI)
   std::vector<uint8_t> kind_;
   std::vector<uint8_t> pending_carry_;   // cbuf(r) not yet folded into the digits
   std::vector<uint32_t> pending_sub_;    // small constant still to subtract (LL's -2)

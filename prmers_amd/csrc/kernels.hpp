@@ -13,6 +13,7 @@ struct DevPlan {
   const uint64_t *S2r, *S2ri, *S1r, *S1ri;   // seam tables of the radix-8 kernels (null when the shape is not served)
   uint64_t I4, I4inv;
   uint64_t W5c[4];   // 5-point DFT constants {beta, k1, k2-k1, k1+k2} (kernels.hip dft5)
+  const uint32_t* DI;   // digit-info words of the v2 column kernels: [tile][thread] 16 x (width - q, wrap), or null
   uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs
 };
 

@@ -371,13 +371,13 @@ __device__ __forceinline__ void stage_r_inv_const(P2 (&x)[8]) {
 }
 
 // weak carry of a run's incoming carry word into its first digits (adc4, marin.cl:203-212)
+// di: the thread's word of the digit-info table (2 bits per digit: width - q, wrap), run = index of the run
+// among the thread's R runs
 template <int ND>
-__device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t T, uint32_t i1, uint64_t cin, uint32_t (&d)[ND]) {
-  const uint32_t sa = pl.SA[i1];
+__device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t di, int run, uint64_t cin, uint32_t (&d)[ND]) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    uint32_t width; bool wr;
-    digit_info(pl, sa, pl.SB[ND * T + k], width, wr);
+    const uint32_t width = pl.q + ((di >> (2 * (run * ND + k))) & 1u);
     const uint64_t v = uint64_t(d[k]) + cin;
     d[k] = uint32_t(v & ((uint64_t(1) << width) - 1));
     cin = v >> width;
@@ -389,24 +389,23 @@ __device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t T, ui
 // sub: small constant to subtract at digit 0 of the whole number, in the field (LL's x^2 - 2).
 template <int R>
 __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T, uint32_t t, uint32_t lane, uint32_t wave,
-                                           const uint32_t (&dg)[R][16 / R], uint32_t sub, uint64_t* __restrict__ Wout) {
+                                           const uint32_t (&dg)[R][16 / R], uint32_t di, uint32_t sub, uint64_t* __restrict__ Wout) {
   using S = ColShape<R>;
   constexpr int C = S::C, LC = S::LC;
   P2 x[8];
+  const uint32_t nowrap = ~di;   // bit 2 idx + 1 of di: the weight exponents of digit idx wrapped
 #pragma unroll
   for (int d1 = 0; d1 < R; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
-    const uint32_t sa = pl.SA[i1], sa1 = pl.SA[S::M1 + i1];       // odd digits: exponent split SA[M1 + i1] + SB[2 i2]
+    // odd digits: exponent split SA[M1 + i1] + SB[2 i2] (plan.hpp), hence their own TA entry
     const uint64_t tah = gf::half(pl.TA[i1]), tah1 = gf::half(pl.TA[S::M1 + i1]);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      uint32_t w0, w1; bool wr0, wr1;
-      const uint32_t sb = pl.SB[2 * C * T + 2 * c];
-      digit_info(pl, sa, sb, w0, wr0);
-      digit_info(pl, sa1, sb, w1, wr1);
       // weight TA*TB, halved when the exponents wrap: the halving is moved onto TA (once per run) and
       // the un-wrapped digits are doubled instead (digits are < 2^21, the product stays a mul_u32)
-      const uint64_t a0 = gf::mul_u32(tah, dg[d1][2 * c] << (wr0 ? 0 : 1)), a1 = gf::mul_u32(tah1, dg[d1][2 * c + 1] << (wr1 ? 0 : 1));
+      const int idx = d1 * S::ND + 2 * c;
+      const uint64_t a0 = gf::mul_u32(tah, dg[d1][2 * c] << ((nowrap >> (2 * idx + 1)) & 1u));
+      const uint64_t a1 = gf::mul_u32(tah1, dg[d1][2 * c + 1] << ((nowrap >> (2 * idx + 3)) & 1u));
       x[C * d1 + c] = {a0, a1};
     }
     if (sub != 0 && T == 0 && i1 == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));   // digit 0 has weight 1
@@ -467,7 +466,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
 template <int R>
 __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, uint32_t t, uint32_t lane, uint32_t wave,
                                           const uint64_t* __restrict__ Win, uint32_t a, uint64_t scale,
-                                          const uint64_t (&carry0)[R], uint32_t (&dg)[R][16 / R], uint64_t (&cout)[R]) {
+                                          const uint64_t (&carry0)[R], uint32_t di, uint32_t (&dg)[R][16 / R], uint64_t (&cout)[R]) {
   using S = ColShape<R>;
   constexpr int C = S::C, LC = S::LC;
   P2 x[8];
@@ -518,27 +517,23 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   dft8p<true>(x);
   // unweighting tables of the carry phase (thread (d2|d3|d4): runs i1 = 512 d1 + t), requested one exchange early;
   // odd digits take theirs from the second half of SA / TAi
-  uint32_t bsa_e[R], bsa_o[R];
   uint64_t btai_e[R], btai_o[R];
 #pragma unroll
-  for (int d1 = 0; d1 < R; ++d1) {
-    bsa_e[d1] = pl.SA[512 * d1 + t]; bsa_o[d1] = pl.SA[S::M1 + 512 * d1 + t];
-    btai_e[d1] = pl.TAi[512 * d1 + t]; btai_o[d1] = pl.TAi[S::M1 + 512 * d1 + t];
-  }
+  for (int d1 = 0; d1 < R; ++d1) { btai_e[d1] = pl.TAi[512 * d1 + t]; btai_o[d1] = pl.TAi[S::M1 + 512 * d1 + t]; }
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
 #define MI355_CALL(W) stage_r_inv_const<R, W>(x)
   MI355_SWITCH8(wave, MI355_CALL)
 #undef MI355_CALL
 #pragma unroll
   for (int d1 = 0; d1 < R; ++d1) {
-    const uint32_t sa_e = bsa_e[d1], sa_o = bsa_o[d1];
     const uint64_t tai_e = btai_e[d1], tai_o = btai_o[d1];
     const uint64_t tai2_e = gf::dbl(tai_e), tai2_o = gf::dbl(tai_o);
     uint64_t carry = carry0[d1];
 #pragma unroll
     for (int k = 0; k < S::ND; ++k) {
-      uint32_t width; bool wrap;
-      digit_info(pl, (k & 1) ? sa_o : sa_e, pl.SB[S::ND * T + (k & ~1)], width, wrap);
+      const uint32_t bits = di >> (2 * (d1 * S::ND + k));   // digit-info table: width - q, wrap
+      const uint32_t width = pl.q + (bits & 1u);
+      const bool wrap = (bits & 2u) != 0;
       const P2 v = x[C * d1 + (k >> 1)];
       const uint64_t u = (k & 1) ? gf::mul(v.b, wrap ? tai2_o : tai_o) : gf::mul(v.a, wrap ? tai2_e : tai_e);   // wrapped exponents: weight was halved
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
@@ -580,13 +575,14 @@ __global__ void __launch_bounds__(512, 4) k1_cols(DevPlan pl, const uint32_t* __
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
   uint32_t dg[R][16 / R];
+  const uint32_t di = pl.DI[size_t(T) * 512 + t];
 #pragma unroll
   for (int d1 = 0; d1 < R; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
     load_run<R>(digits, T, i1, dg[d1]);
-    if (cbuf_in) apply_carry_in<16 / R>(pl, T, i1, carry_in_of(pl, cbuf_in, T, i1), dg[d1]);
+    if (cbuf_in) apply_carry_in<16 / R>(pl, di, d1, carry_in_of(pl, cbuf_in, T, i1), dg[d1]);
   }
-  front_tile<R>(pl, X, T, t, lane, wave, dg, sub, Wout);
+  front_tile<R>(pl, X, T, t, lane, wave, dg, di, sub, Wout);
 }
 
 // back sweep: work buffer -> digits + one carry word per run
@@ -599,7 +595,7 @@ __global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __
   uint64_t cout[R], zero[R];
 #pragma unroll
   for (int d1 = 0; d1 < R; ++d1) zero[d1] = 0;
-  back_tile<R>(pl, X, T, t, lane, wave, Win, a, scale, zero, dg, cout);
+  back_tile<R>(pl, X, T, t, lane, wave, Win, a, scale, zero, pl.DI[size_t(T) * 512 + t], dg, cout);
 #pragma unroll
   for (int d1 = 0; d1 < R; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
@@ -631,7 +627,7 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
     const uint32_t T = (s == 1) ? 2 * b + 1 : 2 * b;
     if (s < 2) {
       uint64_t cout[2];
-      back_tile<2>(pl, X, T, t, lane, wave, Wbuf, a, 1, co, dnew, cout);
+      back_tile<2>(pl, X, T, t, lane, wave, Wbuf, a, 1, co, pl.DI[size_t(T) * 512 + t], dnew, cout);
       co[0] = cout[0]; co[1] = cout[1];
     }
     if (s == 0) {
@@ -668,10 +664,10 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
         const uint64_t cin = __hip_atomic_load(cw + size_t(pb) * 1024 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < 8; ++k) dnew[d1][k] = dhold[d1][k];
-        apply_carry_in<8>(pl, T, i1, cin, dnew[d1]);
+        apply_carry_in<8>(pl, pl.DI[size_t(T) * 512 + t], d1, cin, dnew[d1]);
       }
     }
-    front_tile<2>(pl, X, T, t, lane, wave, dnew, 0, Wbuf);
+    front_tile<2>(pl, X, T, t, lane, wave, dnew, pl.DI[size_t(T) * 512 + t], 0, Wbuf);
   }
 }
 
@@ -682,7 +678,8 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
 bool v2_rows_supported(const DevPlan& pl) { return (pl.M2 == 4096 || pl.M2 == 8192) && pl.S2r != nullptr; }
 // columns: M1 = 512 R, R in {1, 2, 4}, with C = 8 / R pairs per run (one 4096-pair tile per work-group)
 bool v2_cols_supported(const DevPlan& pl) {
-  return pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048) && pl.M1 * pl.C == 4096 && pl.M2 >= pl.C * 2 && pl.S1r != nullptr;
+  return pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048) && pl.M1 * pl.C == 4096 && pl.M2 >= pl.C * 2 && pl.S1r != nullptr &&
+         pl.DI != nullptr;
 }
 
 #define MI355_SET_LDS(KERNEL, BYTES)                                                                                          \

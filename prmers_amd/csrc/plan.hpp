@@ -65,6 +65,9 @@ struct Plan {
   // seam twiddles of the radix-8 kernels, laid out [b][ka] so that a wave reads runs of consecutive entries:
   // S2r[b*64+ka] = omega_4096^(ka*b) (rows of 4096 = 64 x 64), S1r[b*(M1/64)+ka] = omega_M1^(ka*b) (columns M1 = 512/1024/2048 = (M1/64) x 64); *i = inverses
   std::vector<uint64_t> S2r, S2ri, S1r, S1ri;
+  // register-resident column kernels: one word per (tile, thread) with 2 bits per digit of the thread's 16
+  // digits (run d1 = 0..R-1 of i1 = 512 d1 + t, digit k of the run at bits 2 (d1 2C + k)): width - q, wrap
+  std::vector<uint32_t> DI;
   uint64_t I4 = 0, I4inv = 0;            // omega_4, omega_4^-1 (forward root convention)
   uint64_t W5[5] = {1, 0, 0, 0, 0}, W5i[5] = {1, 0, 0, 0, 0};
   uint64_t W5c[4] = {0, 0, 0, 0};        // 5-point DFT constants {beta, k1, k2-k1, k1+k2} (kernels.hip dft5)
@@ -209,6 +212,23 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   }
   if (m % 4 == 0) { pl.I4 = gf::pow(om, m / 4); pl.I4inv = gf::inv(pl.I4); }
   else { pl.I4 = gf::root_of_unity(4); pl.I4inv = gf::inv(pl.I4); }
+  if (!pl.S1r.empty() && size_t(pl.M1) * pl.C == 4096) {
+    const uint32_t R = pl.M1 / 512, ND = 2 * pl.C;
+    pl.DI.assign(pl.tiles() * 512, 0u);
+    for (size_t T = 0; T < pl.tiles(); ++T)
+      for (uint32_t t = 0; t < 512; ++t) {
+        uint32_t w = 0;
+        for (uint32_t d1 = 0; d1 < R; ++d1)
+          for (uint32_t k = 0; k < ND; ++k) {
+            const uint32_t i1 = 512 * d1 + t, i2 = uint32_t(T) * pl.C + (k >> 1);
+            const uint64_t sb = pl.SB[2 * i2 + (k & 1)], s = (uint64_t(pl.SA[i1]) + sb) % n;
+            const uint64_t wa = (k & 1) ? pl.SA[pl.M1 + i1] : pl.SA[i1], wb = pl.SB[2 * i2];   // the split the kernels weight with
+            const uint32_t wbit = pl.width_of_s(s) - pl.q, wrap = (wa > 0 && wb > 0 && wa + wb <= n) ? 1u : 0u;
+            w |= (wbit | (wrap << 1)) << (2 * (d1 * ND + k));
+          }
+        pl.DI[T * 512 + t] = w;
+      }
+  }
   if (pl.I4 != (uint64_t(1) << 48)) throw std::runtime_error("internal: omega_4 is expected to be 2^48");   // the kernels shift instead of multiplying
   if (pl.r5 == 5) {
     const uint64_t w5 = gf::pow(om, m / 5);
