@@ -379,7 +379,7 @@ __device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t di, i
   for (int k = 0; k < 3; ++k) {
     const uint32_t width = pl.q + ((di >> (2 * (run * ND + k))) & 1u);
     const uint64_t v = uint64_t(d[k]) + cin;
-    d[k] = uint32_t(v & ((uint64_t(1) << width) - 1));
+    d[k] = __builtin_amdgcn_ubfe(uint32_t(v), 0u, width);
     cin = v >> width;
   }
   d[3] += uint32_t(cin);
@@ -539,7 +539,7 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
       if (a == 1) {               // the common case (uniform): no 64-bit multiplies
         const uint64_t r = u + carry;                      // u < P, carry < 2^48: no wrap
-        dg[d1][k] = uint32_t(r & mask);
+        dg[d1][k] = __builtin_amdgcn_ubfe(uint32_t(r), 0u, width);   // width < 32: one bit-field extract
         carry = r >> width;
       } else {
         const uint64_t dlo = u & mask, chi = u >> width;
