@@ -73,7 +73,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
 
   dp_.n = uint32_t(pl_.n); dp_.m = uint32_t(pl_.m);
   dp_.M1 = pl_.M1; dp_.M2 = pl_.M2; dp_.L1 = pl_.L1; dp_.logL1 = pl_.logL1; dp_.logM2 = pl_.logM2;
-  dp_.r5 = pl_.r5; dp_.C = pl_.C; dp_.q = pl_.q; dp_.t = pl_.t; dp_.twh = pl_.twh;
+  dp_.r5 = pl_.r5; dp_.C = pl_.C; dp_.logC = 0; while ((1u << dp_.logC) < pl_.C) ++dp_.logC; dp_.q = pl_.q; dp_.t = pl_.t; dp_.twh = pl_.twh;
   dp_.I4 = pl_.I4; dp_.I4inv = pl_.I4inv;
   dp_.DI = nullptr;
   if (!pl_.DI.empty()) {

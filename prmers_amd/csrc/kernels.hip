@@ -37,7 +37,7 @@ __device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
 
 // column-DFT output slot -> frequency k1 (radix-5 block major, bit reversed inside the block)
 __device__ __forceinline__ uint32_t freq1(const DevPlan& pl, uint32_t pos) {
-  const uint32_t blk = pos / pl.L1, q = pos - blk * pl.L1;
+  const uint32_t blk = pos >> pl.logL1, q = pos & (pl.L1 - 1);   // L1 is a power of two
   const uint32_t rq = pl.logL1 ? (__brev(q) >> (32 - pl.logL1)) : 0u;
   return blk + pl.r5 * rq;
 }
@@ -56,7 +56,7 @@ __device__ __forceinline__ void digit_info(const DevPlan& pl, uint32_t sa, uint3
 // length L (blocks x columns) are processed by the whole work-group.  root[e * rstep] = omega_L^e.
 // ---------------------------------------------------------------------------------------------
 template <bool INVERSE>
-__device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, uint32_t nblocks, uint32_t ncols,
+__device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, uint32_t nblocks, uint32_t ncols, uint32_t logcols,
                                              const uint64_t* __restrict__ root, uint32_t rootN, uint32_t rstep,
                                              uint64_t I4, uint32_t tid, uint32_t nthr) {
   // forward: len = L, L/4, ... (radix-4) then a final radix-2 when log2 L is odd; inverse mirrors
@@ -70,9 +70,10 @@ __device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, u
       const uint32_t total = per * nblocks * ncols;
       const uint32_t tstep = (L >> loglen) * rstep;  // omega_len^t = root[t * tstep]
       for (uint32_t idx = tid; idx < total; idx += nthr) {
-        const uint32_t col = idx % ncols, bi = idx / ncols;
-        const uint32_t blk = bi / per, bj = bi - blk * per;
-        const uint32_t sub = bj / q, t = bj - sub * q;
+        // ncols, per and q are powers of two: shifts and masks, no integer division in the loop
+        const uint32_t col = idx & (ncols - 1), bi = idx >> logcols;
+        const uint32_t blk = bi >> (logL - 2), bj = bi & (per - 1);
+        const uint32_t sub = bj >> (loglen - 2), t = bj & (q - 1);
         const uint32_t e0 = (blk * L + sub * len + t) * ncols + col, es = q * ncols;
         const uint32_t r1 = t * tstep;
         P2 x0 = X[e0], x1 = X[e0 + es], x2 = X[e0 + 2 * es], x3 = X[e0 + 3 * es];
@@ -100,8 +101,8 @@ __device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, u
       // radix-2, len = 2: no twiddle
       const uint32_t per = L >> 1, total = per * nblocks * ncols;
       for (uint32_t idx = tid; idx < total; idx += nthr) {
-        const uint32_t col = idx % ncols, bi = idx / ncols;
-        const uint32_t blk = bi / per, bj = bi - blk * per;
+        const uint32_t col = idx & (ncols - 1), bi = idx >> logcols;
+        const uint32_t blk = bi >> (logL - 1), bj = bi & (per - 1);
         const uint32_t e0 = (blk * L + 2 * bj) * ncols + col;
         const P2 u = X[e0], v = X[e0 + ncols];
         X[e0] = p2_add(u, v);
@@ -137,7 +138,7 @@ template <bool INVERSE>
 __device__ __forceinline__ void lds_radix5(const DevPlan& pl, P2* X, uint32_t ncols, uint32_t tid, uint32_t nthr) {
   const uint32_t L1 = pl.L1, total = L1 * ncols;
   for (uint32_t idx = tid; idx < total; idx += nthr) {
-    const uint32_t col = idx % ncols, t = idx / ncols;
+    const uint32_t col = idx & (ncols - 1), t = idx >> pl.logC;   // ncols = C
     P2 x[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) x[r] = X[(L1 * r + t) * ncols + col];
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
   const uint2* dg = reinterpret_cast<const uint2*>(digits) + size_t(T) * tile;
 
   for (uint32_t e = tid; e < tile; e += nthr) {
-    const uint32_t i1 = e / C, c = e - i1 * C, i2 = T * C + c;
+    const uint32_t i1 = e >> pl.logC, c = e & (C - 1), i2 = T * C + c;
     uint2 d = dg[e];
     const uint32_t sa = pl.SA[i1];
     if (cbuf_in && c < 2) {
@@ -212,13 +213,13 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
   __syncthreads();
 
   if (pl.r5 == 5) lds_radix5<false>(pl, X, C, tid, nthr);
-  if (pl.logL1) lds_pow2_dft<false>(X, pl.L1, pl.logL1, pl.r5, C, pl.UT1, M1, pl.r5, pl.I4, tid, nthr);
+  if (pl.logL1) lds_pow2_dft<false>(X, pl.L1, pl.logL1, pl.r5, C, pl.logC, pl.UT1, M1, pl.r5, pl.I4, tid, nthr);
 
   P2* W = reinterpret_cast<P2*>(Wout);
   for (uint32_t e = tid; e < tile; e += nthr) {
-    const uint32_t pos = e / C, c = e - pos * C, i2 = T * C + c;
+    const uint32_t pos = e >> pl.logC, c = e & (C - 1), i2 = T * C + c;
     const uint32_t k1 = freq1(pl, pos);
-    const uint64_t ex = (uint64_t(i2) * k1) % pl.m;
+    const uint32_t ex = i2 * k1;   // i2 < M2, k1 < M1: below m, no reduction needed
     const uint64_t tw = tw_lookup(pl, ex);
     const P2 x = X[e];
     W[size_t(pos) * pl.M2 + i2] = {gf::mul(x.a, gf::mul(tw, pl.TB[2 * i2])), gf::mul(x.b, gf::mul(tw, pl.TB[2 * i2 + 1]))};
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __r
   // deferred small subtraction on a front image (digit 0 -> column 0, plane a of every row, weight 1)
   if (sub != 0 && tid == 0) X[0].a = gf::sub(X[0].a, uint64_t(sub));
   __syncthreads();
-  lds_pow2_dft<false>(X, M2, pl.logM2, 1, 1, pl.UT2, M2, 1, pl.I4, tid, nthr);
+  lds_pow2_dft<false>(X, M2, pl.logM2, 1, 1, 0, pl.UT2, M2, 1, pl.I4, tid, nthr);
   if (mode == 2) {
     for (uint32_t e = tid; e < M2; e += nthr) out[e] = X[e];
     return;
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __r
     X[e] = r;
   }
   __syncthreads();
-  lds_pow2_dft<true>(X, M2, pl.logM2, 1, 1, pl.UT2, M2, 1, pl.I4inv, tid, nthr);
+  lds_pow2_dft<true>(X, M2, pl.logM2, 1, 1, 0, pl.UT2, M2, 1, pl.I4inv, tid, nthr);
   for (uint32_t e = tid; e < M2; e += nthr) out[e] = X[e];
 }
 
@@ -278,16 +279,16 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
   const P2* W = reinterpret_cast<const P2*>(Win);
 
   for (uint32_t e = tid; e < tile; e += nthr) {
-    const uint32_t pos = e / C, c = e - pos * C, i2 = T * C + c;
+    const uint32_t pos = e >> pl.logC, c = e & (C - 1), i2 = T * C + c;
     const uint32_t k1 = freq1(pl, pos);
-    const uint64_t ex = (uint64_t(i2) * k1) % pl.m;
+    const uint32_t ex = i2 * k1;   // i2 < M2, k1 < M1: below m, no reduction needed
     const uint64_t tw = tw_lookup(pl, ex ? pl.m - ex : 0);
     const P2 x = W[size_t(pos) * pl.M2 + i2];
     X[e] = {gf::mul(x.a, gf::mul(tw, pl.TBi[2 * i2])), gf::mul(x.b, gf::mul(tw, pl.TBi[2 * i2 + 1]))};
   }
   __syncthreads();
 
-  if (pl.logL1) lds_pow2_dft<true>(X, pl.L1, pl.logL1, pl.r5, C, pl.UT1, M1, pl.r5, pl.I4inv, tid, nthr);
+  if (pl.logL1) lds_pow2_dft<true>(X, pl.L1, pl.logL1, pl.r5, C, pl.logC, pl.UT1, M1, pl.r5, pl.I4inv, tid, nthr);
   if (pl.r5 == 5) lds_radix5<true>(pl, X, C, tid, nthr);
 
   uint2* dg = reinterpret_cast<uint2*>(digits) + size_t(T) * tile;

@@ -6,7 +6,7 @@
 namespace mi355 {
 
 struct DevPlan {
-  uint32_t n, m, M1, M2, L1, logL1, logM2, r5, C, q, t, twh;
+  uint32_t n, m, M1, M2, L1, logL1, logM2, r5, C, logC, q, t, twh;
   const uint32_t *SA, *SB;
   const uint64_t *TA, *TAi, *TB, *TBi;
   const uint64_t *TWlo, *TWhi, *UT1, *UT2;

@@ -426,7 +426,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   // four-step twiddle ingredients for the last stage (thread (k3|k1|k2|c)), requested two exchanges early
   const uint32_t fc = t & (C - 1), fkb = ((t >> (3 + LC)) & (R - 1)) + R * ((t >> LC) & 7) + 8 * R * (t >> 6), fi2 = C * T + fc;
-  const uint64_t feA = (uint64_t(fi2) * fkb) % pl.m, feB = (uint64_t(fi2) * (64 * R)) % pl.m;
+  const uint32_t feA = fi2 * fkb, feB = fi2 * (64 * R);   // fi2 < M2, fkb < M1 / 8: both below m, no reduction needed
   const uint64_t fAl = pl.TWlo[feA & ((1u << pl.twh) - 1)], fAh = pl.TWhi[feA >> pl.twh];
   const uint64_t fBl = pl.TWlo[feB & ((1u << pl.twh) - 1)], fBh = pl.TWhi[feB >> pl.twh];
   const uint64_t fTB0 = pl.TB[2 * fi2];
@@ -474,7 +474,7 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
     const uint32_t c = t & (C - 1), k2 = (t >> LC) & 7, k1 = (t >> (3 + LC)) & (R - 1), k3 = t >> 6;
     const uint32_t kb = k1 + R * k2 + 8 * R * k3;
     const uint32_t i2 = C * T + c;
-    const uint64_t ea = (uint64_t(i2) * kb) % pl.m, eb = (uint64_t(i2) * (64 * R)) % pl.m;
+    const uint32_t ea = i2 * kb, eb = i2 * (64 * R);   // below m (i2 < M2, kb < M1 / 8)
     uint64_t A = tw_lookup(pl, ea ? pl.m - ea : 0);
     const uint64_t B = tw_lookup(pl, eb ? pl.m - eb : 0);
     if (scale != 1) A = gf::mul(A, scale);
