@@ -201,13 +201,15 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
         d = c ? make_uint2(dd[2], dd[3]) : make_uint2(dd[0], dd[1]);
       }
     }
-    const uint64_t ta = pl.TA[i1];
+    // weight = TA * TB / (wrap ? 2 : 1).  The odd digit takes its exponent split from the second half of
+    // SA / TA (plan.hpp) so that both digits of the pair share the column factor TB[2 i2]; the halving sits
+    // on TA and the digits that do not wrap are doubled instead (digits are < 2^21: still a mul_u32).
     uint32_t w0, w1; bool wr0, wr1;
-    digit_info(pl, sa, pl.SB[2 * i2], w0, wr0);
-    digit_info(pl, sa, pl.SB[2 * i2 + 1], w1, wr1);
-    uint64_t a0 = gf::mul_u32(ta, d.x), a1 = gf::mul_u32(ta, d.y);
-    if (wr0) a0 = gf::half(a0);
-    if (wr1) a1 = gf::half(a1);
+    const uint32_t sb = pl.SB[2 * i2];
+    digit_info(pl, sa, sb, w0, wr0);
+    digit_info(pl, pl.SA[M1 + i1], sb, w1, wr1);
+    const uint64_t a0 = gf::mul_u32(gf::half(pl.TA[i1]), d.x << (wr0 ? 0 : 1));
+    const uint64_t a1 = gf::mul_u32(gf::half(pl.TA[M1 + i1]), d.y << (wr1 ? 0 : 1));
     X[e] = {a0, a1};
   }
   __syncthreads();
@@ -222,7 +224,8 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
     const uint32_t ex = i2 * k1;   // i2 < M2, k1 < M1: below m, no reduction needed
     const uint64_t tw = tw_lookup(pl, ex);
     const P2 x = X[e];
-    W[size_t(pos) * pl.M2 + i2] = {gf::mul(x.a, gf::mul(tw, pl.TB[2 * i2])), gf::mul(x.b, gf::mul(tw, pl.TB[2 * i2 + 1]))};
+    const uint64_t twb = gf::mul(tw, pl.TB[2 * i2]);
+    W[size_t(pos) * pl.M2 + i2] = {gf::mul(x.a, twb), gf::mul(x.b, twb)};
   }
 }
 
@@ -284,7 +287,8 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
     const uint32_t ex = i2 * k1;   // i2 < M2, k1 < M1: below m, no reduction needed
     const uint64_t tw = tw_lookup(pl, ex ? pl.m - ex : 0);
     const P2 x = W[size_t(pos) * pl.M2 + i2];
-    X[e] = {gf::mul(x.a, gf::mul(tw, pl.TBi[2 * i2])), gf::mul(x.b, gf::mul(tw, pl.TBi[2 * i2 + 1]))};
+    const uint64_t twb = gf::mul(tw, pl.TBi[2 * i2]);   // one column factor per pair (see k_front)
+    X[e] = {gf::mul(x.a, twb), gf::mul(x.b, twb)};
   }
   __syncthreads();
 
@@ -293,25 +297,31 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
 
   uint2* dg = reinterpret_cast<uint2*>(digits) + size_t(T) * tile;
   for (uint32_t i1 = tid; i1 < M1; i1 += nthr) {
-    const uint32_t sa = pl.SA[i1];
-    const uint64_t tai = pl.TAi[i1];
+    const uint32_t sa[2] = {pl.SA[i1], pl.SA[M1 + i1]};          // even / odd digit (second half: see k_front)
+    const uint64_t tai[2] = {pl.TAi[i1], pl.TAi[M1 + i1]};
+    const uint64_t tai2[2] = {gf::dbl(tai[0]), gf::dbl(tai[1])};  // wrapped exponents: the weight was halved
     uint64_t carry = 0;
     for (uint32_t c = 0; c < C; ++c) {
       const uint32_t i2 = T * C + c;
       const P2 x = X[i1 * C + c];
+      const uint32_t sb = pl.SB[2 * i2];
       uint32_t out[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         uint32_t width; bool wrap;
-        digit_info(pl, sa, pl.SB[2 * i2 + b], width, wrap);
-        uint64_t u = gf::mul(b ? x.b : x.a, tai);
-        if (wrap) u = gf::dbl(u);
-        // adc_mul (marin.cl:194-201): digit first, so that everything stays in 64 bits
+        digit_info(pl, sa[b], sb, width, wrap);
+        const uint64_t u = gf::mul(b ? x.b : x.a, wrap ? tai2[b] : tai[b]);
         const uint64_t mask = (uint64_t(1) << width) - 1;
-        const uint64_t dlo = u & mask, chi = u >> width;
-        const uint64_t r = dlo * a + carry;
-        out[b] = uint32_t(r & mask);
-        carry = (r >> width) + chi * a;
+        if (a == 1) {               // the common case (uniform): no 64-bit multiplies
+          const uint64_t r = u + carry;   // u < P, carry < 2^48: no wrap
+          out[b] = uint32_t(r & mask);
+          carry = r >> width;
+        } else {                    // adc_mul (marin.cl:194-201): digit first, so that everything stays in 64 bits
+          const uint64_t dlo = u & mask, chi = u >> width;
+          const uint64_t r = dlo * a + carry;
+          out[b] = uint32_t(r & mask);
+          carry = (r >> width) + chi * a;
+        }
       }
       dg[i1 * C + c] = make_uint2(out[0], out[1]);
     }
