@@ -37,6 +37,15 @@ def test_plan_policy_matches_reference_sizes():
         assert m1 * m2 * 2 == n and m2 % c == 0 and lf <= 160 * 1024 and lm <= 160 * 1024
 
 
+def test_plan_weight_tables_and_digit_info_words():
+    """plan.hpp: digit widths, both factorisations of the IBDWT weights (incl. the second half of SA/TA used
+    for odd digits), the inverse tables and the 2-bit-per-digit DI words, digit by digit against the defining
+    formulas (ibdwt.h:111-147: width = ceil(p(j+1)/n) - ceil(pj/n), w_j = 2^((n - pj mod n)/n))."""
+    out = _build_and_run("test_plan_tables.cpp")
+    assert out.strip().endswith("OK"), out
+    assert "di_checked=16384" in out and "di_checked=32768" in out   # the register-resident column shapes were covered
+
+
 def test_c_abi_exports_and_no_gpu_behaviour():
     """the library loads, exports every symbol the header declares, resolves plans without a GPU and
     refuses to create an engine without one (no CPU fallback)."""
