@@ -76,6 +76,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   dp_.r5 = pl_.r5; dp_.C = pl_.C; dp_.logC = 0; while ((1u << dp_.logC) < pl_.C) ++dp_.logC; dp_.q = pl_.q; dp_.t = pl_.t; dp_.twh = pl_.twh;
   dp_.I4 = pl_.I4; dp_.I4inv = pl_.I4inv;
   dp_.DI = nullptr;
+  dp_.F0f = dp_.F0i = dp_.FBf = dp_.FBi = nullptr;
   if (!pl_.DI.empty()) {
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&di_), pl_.DI.size() * 4));
     HIPCHK(hipMemcpy(di_, pl_.DI.data(), pl_.DI.size() * 4, hipMemcpyHostToDevice));
@@ -92,6 +93,13 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     v2rows_ = (sel == "v2" || sel == "v2rows") && v2_rows_supported(dp_);
     v2cols_ = (sel == "v2" || sel == "v2cols") && v2_cols_supported(dp_);
     if (v2rows_ || v2cols_) HIPCHK(v2_configure());
+    if (v2cols_) {   // four-step chain starts and ratios: built once on the device (2 x tiles x 512 + 2 x M2 words)
+      const size_t nt = pl_.tiles() * 512;
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&f0_), (2 * nt + 2 * size_t(pl_.M2)) * 8));
+      HIPCHK(v2_build_fourstep(dp_, f0_, f0_ + nt, f0_ + 2 * nt, f0_ + 2 * nt + pl_.M2, stream_));
+      HIPCHK(hipStreamSynchronize(stream_));
+      dp_.F0f = f0_; dp_.F0i = f0_ + nt; dp_.FBf = f0_ + 2 * nt; dp_.FBi = f0_ + 2 * nt + pl_.M2;
+    }
     // fused back+front sweep: the residue stays in the work-buffer layout between squarings
     // (measured at C3: 0.222 ms/iter fused vs 0.213 unfused -- the sweeps are VALU-bound, so saving the digit
     // round trip buys nothing yet; kept selectable with MI355_FUSED=1, off by default)
@@ -125,6 +133,7 @@ Engine::~Engine() {
   if (cbuf_) (void)hipFree(cbuf_);
   if (tables_) (void)hipFree(tables_);
   if (di_) (void)hipFree(di_);
+  if (f0_) (void)hipFree(f0_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 

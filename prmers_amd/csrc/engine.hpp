@@ -92,6 +92,7 @@ class Engine {
   bool fused_ = false;
   uint64_t* cbuf_ = nullptr;
   void* tables_ = nullptr;
+  uint64_t* f0_ = nullptr;   // four-step chain starts / ratios of the register-resident column kernels
   uint32_t* di_ = nullptr;   // digit-info words of the register-resident column kernels (plan.hpp DI)
   std::vector<uint8_t> kind_;
   std::vector<uint8_t> pending_carry_;   // cbuf(r) not yet folded into the digits

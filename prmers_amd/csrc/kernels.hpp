@@ -13,6 +13,7 @@ struct DevPlan {
   const uint64_t *S2r, *S2ri, *S1r, *S1ri;   // seam tables of the radix-8 kernels (null when the shape is not served)
   uint64_t I4, I4inv;
   uint64_t W5c[4];   // 5-point DFT constants {beta, k1, k2-k1, k1+k2} (kernels.hip dft5)
+  const uint64_t *F0f, *F0i, *FBf, *FBi;   // four-step chain starts [tile][thread] and ratios [column] of the v2 column kernels
   const uint32_t* DI;   // digit-info words of the v2 column kernels: [tile][thread] 16 x (width - q, wrap), or null
   uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs
 };
@@ -31,6 +32,8 @@ hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hip
 bool v2_rows_supported(const DevPlan& pl);
 bool v2_cols_supported(const DevPlan& pl);
 hipError_t v2_configure();
+// fills the chain-start / ratio tables of the column kernels' four-step twiddles (tiles*512, tiles*512, M2, M2 words)
+hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, uint64_t* fbf, uint64_t* fbi, hipStream_t s);
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s);

@@ -426,10 +426,8 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   // four-step twiddle ingredients for the last stage (thread (k3|k1|k2|c)), requested two exchanges early
   const uint32_t fc = t & (C - 1), fkb = ((t >> (3 + LC)) & (R - 1)) + R * ((t >> LC) & 7) + 8 * R * (t >> 6), fi2 = C * T + fc;
-  const uint32_t feA = fi2 * fkb, feB = fi2 * (64 * R);   // fi2 < M2, fkb < M1 / 8: both below m, no reduction needed
-  const uint64_t fAl = pl.TWlo[feA & ((1u << pl.twh) - 1)], fAh = pl.TWhi[feA >> pl.twh];
-  const uint64_t fBl = pl.TWlo[feB & ((1u << pl.twh) - 1)], fBh = pl.TWhi[feB >> pl.twh];
-  const uint64_t fTB0 = pl.TB[2 * fi2];
+  // chain start omega_m^(i2 kb) TB[2 i2] and ratio omega_m^(64R i2), ready-made per (tile, thread) / per column
+  const uint64_t fca0 = pl.F0f[size_t(T) * 512 + t], fB = pl.FBf[fi2];
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false, 1>(x);
   seam64<false, true>(x, wave);
@@ -446,9 +444,8 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   dft8p<false, 2>(x);   // four-step twiddle next
   {
     const uint32_t kb = fkb, i2 = fi2;
-    const uint64_t A = gf::mul(fAl, fAh);
-    const uint64_t B = gf::mul(fBl, fBh);
-    uint64_t ca = gf::mul(A, fTB0);   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
+    const uint64_t B = fB;
+    uint64_t ca = fca0;   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
     const uint32_t row0 = __brev(kb) >> (32 - S::LM);   // bitrev(kb): its low 3 bits are zero
     P2* W = reinterpret_cast<P2*>(Wout);
 #pragma unroll
@@ -474,11 +471,10 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
     const uint32_t c = t & (C - 1), k2 = (t >> LC) & 7, k1 = (t >> (3 + LC)) & (R - 1), k3 = t >> 6;
     const uint32_t kb = k1 + R * k2 + 8 * R * k3;
     const uint32_t i2 = C * T + c;
-    const uint32_t ea = i2 * kb, eb = i2 * (64 * R);   // below m (i2 < M2, kb < M1 / 8)
-    uint64_t A = tw_lookup(pl, ea ? pl.m - ea : 0);
-    const uint64_t B = tw_lookup(pl, eb ? pl.m - eb : 0);
-    if (scale != 1) A = gf::mul(A, scale);
-    uint64_t ca = gf::mul(A, pl.TBi[2 * i2]);   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
+    // chain start omega_m^-(i2 kb) TBi[2 i2] and ratio omega_m^-(64R i2), ready-made (k_build_f0)
+    uint64_t ca = pl.F0i[size_t(T) * 512 + t];   // one chain for both digits of a pair (plan.hpp: SA/TA second half)
+    const uint64_t B = pl.FBi[i2];
+    if (scale != 1) ca = gf::mul(ca, scale);
     const uint32_t row0 = __brev(kb) >> (32 - S::LM);
     const P2* W = reinterpret_cast<const P2*>(Win);
 #pragma unroll
@@ -672,6 +668,38 @@ __global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* _
 }
 
 }  // namespace v2
+
+namespace v2 {
+// chain starts and ratios of the four-step twiddle chains of the column kernels (same thread map as the last
+// stage of front_tile / first stage of back_tile): F0f[T][t] = omega_m^(i2 kb) TB[2 i2], F0i the inverse with
+// TBi, FBf[i2] = omega_m^(64R i2), FBi its inverse.
+template <int R>
+__global__ void __launch_bounds__(512) k_build_f0(DevPlan pl, uint64_t* __restrict__ f0f, uint64_t* __restrict__ f0i,
+                                                  uint64_t* __restrict__ fbf, uint64_t* __restrict__ fbi) {
+  using S = ColShape<R>;
+  constexpr int C = S::C, LC = S::LC;
+  const uint32_t t = threadIdx.x, T = blockIdx.x;
+  const uint32_t c = t & (C - 1), kb = ((t >> (3 + LC)) & (R - 1)) + R * ((t >> LC) & 7) + 8 * R * (t >> 6), i2 = C * T + c;
+  const uint32_t ea = i2 * kb;
+  f0f[size_t(T) * 512 + t] = gf::mul(tw_lookup(pl, ea), pl.TB[2 * i2]);
+  f0i[size_t(T) * 512 + t] = gf::mul(tw_lookup(pl, ea ? pl.m - ea : 0), pl.TBi[2 * i2]);
+  if (t < C) {
+    const uint32_t eb = i2 * (64 * R);
+    fbf[i2] = tw_lookup(pl, eb);
+    fbi[i2] = tw_lookup(pl, eb ? pl.m - eb : 0);
+  }
+}
+}  // namespace v2
+
+hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, uint64_t* fbf, uint64_t* fbi, hipStream_t s) {
+  const dim3 grid(pl.M2 / pl.C), block(512);
+  switch (pl.M1) {
+    case 512: hipLaunchKernelGGL(v2::k_build_f0<1>, grid, block, 0, s, pl, f0f, f0i, fbf, fbi); break;
+    case 1024: hipLaunchKernelGGL(v2::k_build_f0<2>, grid, block, 0, s, pl, f0f, f0i, fbf, fbi); break;
+    default: hipLaunchKernelGGL(v2::k_build_f0<4>, grid, block, 0, s, pl, f0f, f0i, fbf, fbi); break;
+  }
+  return hipGetLastError();
+}
 
 // ------------------------------- launch wrappers ---------------------------------------------
 
