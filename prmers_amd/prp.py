@@ -28,32 +28,34 @@ CKPT_BACKEND_ID = 3      # 1 = Marin/OpenCL, 2 = Aevum (RunPrpOrLlMarin.cpp:154)
 # residue formatting (AlgoUtils.hpp:165-223, engine.h:257-295)
 # ---------------------------------------------------------------------------------------------
 def pack_words(digits, p):
-    """little-endian 32-bit words of an encoded digit vector (value | width << 32)."""
-    v, s = 0, 0
-    for x in np.asarray(digits, dtype=np.uint64).tolist():
-        w = x >> 32
-        v |= (x & ((1 << w) - 1) & 0xFFFFFFFF) << s
-        s += w
+    """little-endian 32-bit words of an encoded digit vector (value | width << 32); the digits are canonical
+    (value < 2^width), so their bit fields are disjoint and can be scattered with two vector adds."""
+    d = np.asarray(digits, dtype=np.uint64)
+    w = d >> np.uint64(32)
+    v = d & ((np.uint64(1) << w) - np.uint64(1)) & np.uint64(0xFFFFFFFF)
+    off = np.concatenate(([0], np.cumsum(w, dtype=np.uint64)[:-1])).astype(np.uint64)
     wc = (p + 31) // 32
-    return np.frombuffer((v & ((1 << (32 * wc)) - 1)).to_bytes(wc * 4, "little"), dtype="<u4").copy()
+    acc = np.zeros(wc + 2, dtype=np.uint64)
+    sh = v << (off & np.uint64(31))                      # < 2^63: a digit spans at most two words
+    idx = (off >> np.uint64(5)).astype(np.int64)
+    np.add.at(acc, idx, sh & np.uint64(0xFFFFFFFF))
+    np.add.at(acc, idx + 1, sh >> np.uint64(32))
+    return acc[:wc].astype("<u4")
 
 
-def _div3_words(p, W):
-    r = (3 - int(sum(int(w) % 3 for w in W) % 3)) % 3
-    top = p % 32
-    t = (r << top) + int(W[-1])
-    W[-1], r = t // 3, t % 3
-    for i in range(len(W) - 2, -1, -1):
-        t = (r << 32) + int(W[i])
-        W[i], r = t // 3, t % 3
+def _div3(p, x):
+    """x / 3 mod 2^p-1 for odd p: (x + r (2^p - 1)) / 3 with r = -x mod 3 (2^p - 1 = 1 mod 3); the reference does
+    the same division word by word (AlgoUtils.hpp:180-203)."""
+    r = (-x) % 3
+    return (x + r * ((1 << p) - 1)) // 3
 
 
 def prp3_div9(p, W):
     """type-1 residue: divide 3^(2^p) by 9 mod 2^p-1 on the word vector (AlgoUtils.hpp:204-210)."""
-    W = [int(w) for w in W]
-    _div3_words(p, W)
-    _div3_words(p, W)
-    return np.array(W, dtype=np.uint64).astype("<u4")
+    wc = (p + 31) // 32
+    x = int.from_bytes(np.ascontiguousarray(W, dtype="<u4").tobytes(), "little")
+    x = _div3(p, _div3(p, x))
+    return np.frombuffer(x.to_bytes(wc * 4, "little"), dtype="<u4").copy()
 
 
 def format_res64(W):
@@ -65,13 +67,17 @@ def format_res2048(W):
 
 
 def digits_equal_to(digits, a):
-    r = a
-    for x in np.asarray(digits, dtype=np.uint64).tolist():
-        w = x >> 32
-        if (r & ((1 << w) - 1)) != (x & 0xFFFFFFFF):
-            return False
-        r >>= w
-    return True
+    """engine::digit::equal_to (engine.h:272-284): the digit vector spells the small constant a."""
+    d = np.asarray(digits, dtype=np.uint64)
+    w = d >> np.uint64(32)
+    expect = np.zeros(d.size, dtype=np.uint64)
+    r, k = int(a), 0
+    while r and k < d.size:
+        wk = int(w[k])
+        expect[k] = r & ((1 << wk) - 1)
+        r >>= wk
+        k += 1
+    return r == 0 and bool(np.array_equal(d & np.uint64(0xFFFFFFFF), expect))
 
 
 def digits_equal_to_Mp(digits):

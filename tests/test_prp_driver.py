@@ -133,6 +133,34 @@ def test_c2_9815459_partial_run_with_gerbicz_check():
         assert np.array_equal(e.digits(prp.R0), o.digits(0))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [57885161, 136279841])
+def test_gerbicz_blocks_at_register_resident_shapes(p):
+    """n = 2^22 and C3 (n = 2^23), both served end to end by the register-resident kernels: the first two
+    Gerbicz-Li blocks of the real PRP schedule (2*B + 5 squarings of a full-size residue plus the two block
+    verifications, ~45 000 squarings at C3) must pass their checks, and an injected error must be caught."""
+    B = int(p ** 0.5)
+    from prmers_amd import Engine
+    msgs = []
+    with Engine(p, prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, max_iters=2 * B + 5, log=msgs.append)
+        assert r["gerbicz_errors"] == 0 and r["gerbicz_checks"] >= 2, msgs[-5:]
+    msgs = []
+    with Engine(p, prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, max_iters=B + 5, erroriter=100, log=msgs.append)
+        assert r["gerbicz_errors"] >= 1 and any("Check FAILED" in m for m in msgs), msgs[-5:]
+
+
+@pytest.mark.gpu
+def test_full_prp_of_m216091_on_gpu():
+    """a complete PRP of a known Mersenne prime beyond the reference's unit-test list (n = 10240, radix-5
+    shape): 216091 squarings with the Gerbicz-Li check on end on residue 9, type-1 res64 = 1."""
+    from prmers_amd import Engine
+    with Engine(216091, prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, 216091, "prp")
+    assert r["complete"] and r["is_prime"] and r["res64"] == "0000000000000001" and r["gerbicz_errors"] == 0
+
+
 def test_result_json_shape():
     """keys and order of the reference's PRP / LL result JSON (src/io/JsonBuilder.cpp:396-441)."""
     with orc.OracleEngine(127, prp.REGISTERS) as e:
