@@ -6,14 +6,20 @@
 //   * inside a block every root of unity is a power of two (omega_64 = 2^39): butterflies are add/sub
 //     plus constant shifts (gfdft.hpp), the twiddle between the two radix-8 halves of a block is a
 //     shift whose amount is uniform per wavefront (the thread->element maps below put the digit that
-//     selects it in the wave index), so it costs scalar branches, not lane divergence;
+//     selects it in the wave index): the seam is compiled once per wave index with constant shifts and
+//     selected by one scalar switch;
 //   * only the seam between two blocks is a general GF(P) multiplication (one per element and
 //     direction, from a universal omega_M table), against three per radix-4 level pair in the
 //     reference's schedule (marin.cl:304-318: fwd4/bck4 with r1, r23.s0, r23.s1).
-// Shapes served: rows M2 = 4096 (8.8.8.8) and 8192 (2 x 4096 under one radix-2 level); columns M1 = 512 R (R.8.8.8, R = 1, 2, 4) with C = 8/R pairs per
-// run.  Everything else runs on the generic set.  Row order of the work buffer and digit layout are those of kernels.hip,
-// so the two sets interoperate kernel by kernel (the multiplicand image layout differs: an engine
-// uses one middle kernel for both set_multiplicand and mul).
+// Shapes served: rows M2 = 4096 (8.8.8.8) and 8192 (2 x 4096 under one radix-2 level); columns
+// M1 = 512 R (R.8.8.8, R = 1, 2, 4) with C = 8/R pairs per run.  Everything else runs on the generic set.
+// Row order of the work buffer and digit layout are those of kernels.hip, so the two sets interoperate
+// kernel by kernel (the multiplicand image layout differs: an engine uses one middle kernel for both
+// set_multiplicand and mul).
+// Value ranges: field values are canonical ([0, P)) except that (a) a negated zero may be P (gf.hpp,
+// mul_pow2) and (b) sums marked LAZY (gfdft.hpp) may be any 64-bit representative; (b) only ever feeds a
+// multiplication, and every kernel's last arithmetic step before a store is a multiplication or a canonical
+// add/sub, so nothing non-canonical other than P reaches an add/sub operand or a digit.
 //
 // LDS exchanges (P2 = 16 B slots, index skewed by i + i/8 against bank conflicts):
 //   writer "thread-major": slot t*8 + r          reader: slot j*512 + t'
