@@ -101,15 +101,16 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
       dp_.F0f = f0_; dp_.F0i = f0_ + nt; dp_.FBf = f0_ + 2 * nt; dp_.FBi = f0_ + 2 * nt + pl_.M2;
     }
     // fused back+front sweep: the residue stays in the work-buffer layout between squarings
-    // (measured at C3: 0.222 ms/iter fused vs 0.213 unfused -- the sweeps are VALU-bound, so saving the digit
-    // round trip buys nothing yet; kept selectable with MI355_FUSED=1, off by default)
+    // (measured at C3, same box: 0.176 ms/iter fused vs 0.164 unfused -- the fused work-group lives twice as long
+    // at 126 VGPRs and the sweeps are VALU-bound, so saving the digit round trip and one kernel boundary does
+    // not pay; kept selectable with MI355_FUSED=1, off by default)
     const char* fz = std::getenv("MI355_FUSED");
-    fused_ = v2cols_ && pl_.M1 == 1024 && fz && fz[0] == '1';
+    fused_ = v2cols_ && fz && fz[0] == '1';
     if (fused_) {
-      const size_t groups = pl_.M2 / 8;
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&cw_), groups * 1024 * 8));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&flags_), (groups + 16) * 4));
-      HIPCHK(hipMemsetAsync(flags_, 0, (groups + 16) * 4, stream_));
+      const size_t tiles = pl_.tiles();
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&cw_), tiles * pl_.M1 * 8));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&flags_), (tiles + 16) * 4));
+      HIPCHK(hipMemsetAsync(flags_, 0, (tiles + 16) * 4, stream_));
     }
   }
 
@@ -155,7 +156,7 @@ void Engine::sync() {
 void Engine::check_device_error() {
   if (!fused_) return;
   uint32_t e = 0;
-  HIPCHK(hipMemcpy(&e, flags_ + pl_.M2 / 8, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&e, flags_ + pl_.tiles(), 4, hipMemcpyDeviceToHost));
   if (e) throw std::runtime_error("fused sweep: inter-work-group carry hand-off timed out (results invalid)");
 }
 
@@ -392,7 +393,7 @@ void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
     run_middle(image(r), nullptr, image(r), 0, pending_sub_[r]);
     pending_sub_[r] = 0;
     if (ev) HIPCHK(hipEventRecord(ev[2], stream_));
-    HIPCHK(v2_launch_back_front(dp_, image(r), cw_, flags_, ++epoch_, a, flags_ + pl_.M2 / 8, stream_));
+    HIPCHK(v2_launch_back_front(dp_, image(r), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
     if (ev) { HIPCHK(hipEventRecord(ev[3], stream_)); HIPCHK(hipEventRecord(ev[4], stream_)); }
     return;
   }
@@ -446,7 +447,7 @@ void Engine::mul(size_t dst, size_t src, uint32_t a) {
     ensure_front(dst);
     run_middle(image(dst), image(src), image(dst), 1, pending_sub_[dst]);
     pending_sub_[dst] = 0;
-    HIPCHK(v2_launch_back_front(dp_, image(dst), cw_, flags_, ++epoch_, a, flags_ + pl_.M2 / 8, stream_));
+    HIPCHK(v2_launch_back_front(dp_, image(dst), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
     return;
   }
   run_front(dst);

@@ -37,7 +37,7 @@ hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s);
-// fused back + front sweep, in place on a work buffer / front image (cw: [M2/8][1024] carry words, flags: [M2/8])
+// fused back + front sweep, in place on a work buffer / front image (cw: [tiles][M1] carry words, flags: [tiles])
 hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s);
 
 }  // namespace mi355

@@ -607,70 +607,55 @@ __global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused back + front sweep (work buffer -> work buffer, in place), M1 = 1024 only: the residue never goes
-// to memory as digits between two squarings.  A work-group owns the neighbouring tiles A = 2b and B = 2b+1:
-//   back(A) [carry-in 0]  ->  back(B) [carry-in = A's carry-out, same runs, same threads]
-//   -> publish B's carry-out words (write-through stores, then one flag store per work-group)
-//   -> front(B)  ->  wait for the previous work-group's flag, fetch its carry words -> front(A).
-// Only A's carry-in crosses work-groups, and it is needed last, so the wait is normally over before it
-// starts.  No work-group waits before it has published, so the chain cannot deadlock under in-order
-// dispatch; the poll is bounded anyway and reports through *err.  Hand-off protocol:
-// cdna_hip_programming.md Guideline 16, "sc1 stores + drained flag" row (flag = epoch of this launch).
+// Fused back + front sweep (work buffer -> work buffer, in place): the residue never goes to memory as
+// digits between two squarings and one of the three kernel boundaries per squaring disappears.  One tile
+// per work-group:  back(T) [carry-in 0]  ->  publish the R carry-out words per thread (write-through
+// stores, then one flag store per work-group)  ->  wait for tile T-1's flag, fetch its carry words, fold
+// them into the first digits of the runs  ->  front(T).  Tile T-1 belongs to a work-group dispatched
+// earlier (block b - 8 under the XCD-contiguous tile order), which published long before this one finished
+// its own back phase; only the 8 work-groups that start an XCD chunk wait for a late one (the number is
+// cyclic: tile 0 continues the last tile).  No work-group waits before it has published, so the chain cannot
+// deadlock under in-order dispatch; the poll is bounded anyway and reports through *err.  Hand-off
+// protocol: cdna_hip_programming.md Guideline 16, "sc1 stores + drained flag" row (flag = epoch of this launch).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512, 4) k31_cols1024x4(DevPlan pl, uint64_t* __restrict__ Wbuf, uint64_t* __restrict__ cw,
-                                                         uint32_t* __restrict__ flags, uint32_t epoch, uint32_t a, uint32_t* __restrict__ err) {
+template <int R>
+__global__ void __launch_bounds__(512, 4) k31_cols(DevPlan pl, uint64_t* __restrict__ Wbuf, uint64_t* __restrict__ cw,
+                                                   uint32_t* __restrict__ flags, uint32_t epoch, uint32_t a, uint32_t* __restrict__ err) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const uint32_t b = blockIdx.x, G = gridDim.x;
-  uint32_t dnew[2][8], dhold[2][8];
-  uint64_t co[2] = {0, 0};
-#pragma unroll 1
-  for (uint32_t s = 0; s < 3; ++s) {
-    const uint32_t T = (s == 1) ? 2 * b + 1 : 2 * b;
-    if (s < 2) {
-      uint64_t cout[2];
-      back_tile<2>(pl, X, T, t, lane, wave, Wbuf, a, 1, co, pl.DI[size_t(T) * 512 + t], dnew, cout);
-      co[0] = cout[0]; co[1] = cout[1];
+  const uint32_t NT = gridDim.x, T = tile_of_block(pl, blockIdx.x, NT);
+  constexpr uint32_t M1 = 512 * R;
+  const uint32_t di = pl.DI[size_t(T) * 512 + t];
+  uint32_t dg[R][16 / R];
+  uint64_t cout[R], zero[R];
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) zero[d1] = 0;
+  back_tile<R>(pl, X, T, t, lane, wave, Wbuf, a, 1, zero, di, dg, cout);
+  // publish the carry words leaving this tile (they enter tile T + 1, or the next row of tile 0)
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1)
+    __hip_atomic_store(cw + size_t(T) * M1 + 512 * d1 + t, cout[d1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const uint32_t pT = T ? T - 1 : NT - 1;
+  if (t == 0) {
+    __hip_atomic_store(flags + T, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t ok = 0;
+    for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+      if (__hip_atomic_load(flags + pT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
     }
-    if (s == 0) {
-#pragma unroll
-      for (int d1 = 0; d1 < 2; ++d1)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dhold[d1][k] = dnew[d1][k];
-      continue;
-    }
-    if (s == 1) {
-      // publish the carry words leaving tile B (they enter the next work-group's tile A)
-#pragma unroll
-      for (int d1 = 0; d1 < 2; ++d1)
-        __hip_atomic_store(cw + size_t(b) * 1024 + 512 * d1 + t, co[d1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (t == 0) __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      // tile A's runs continue the previous work-group's tile B (work-group 0: the last one, one row up)
-      const uint32_t pb = b ? b - 1 : G - 1;
-      if (t == 0) {
-        uint32_t ok = 0;
-        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-          if (__hip_atomic_load(flags + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = 1; break; }
-          __builtin_amdgcn_s_sleep(8);
-        }
-        if (!ok) atomicOr(err, 1u);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int d1 = 0; d1 < 2; ++d1) {
-        const uint32_t i1 = 512 * d1 + t;
-        const uint32_t pi = b ? i1 : (i1 ? i1 - 1 : 1023);
-        const uint64_t cin = __hip_atomic_load(cw + size_t(pb) * 1024 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dnew[d1][k] = dhold[d1][k];
-        apply_carry_in<8>(pl, pl.DI[size_t(T) * 512 + t], d1, cin, dnew[d1]);
-      }
-    }
-    front_tile<2>(pl, X, T, t, lane, wave, dnew, pl.DI[size_t(T) * 512 + t], 0, Wbuf);
+    if (!ok) atomicOr(err, 1u);
   }
+  __syncthreads();
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) {
+    const uint32_t i1 = 512 * d1 + t;
+    const uint32_t pi = T ? i1 : (i1 ? i1 - 1 : M1 - 1);
+    const uint64_t cin = __hip_atomic_load(cw + size_t(pT) * M1 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    apply_carry_in<16 / R>(pl, di, d1, cin, dg[d1]);
+  }
+  front_tile<R>(pl, X, T, t, lane, wave, dg, di, 0, Wbuf);
 }
 
 }  // namespace v2
@@ -724,7 +709,7 @@ hipError_t v2_configure() {
   MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes)
   MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
-  MI355_SET_LDS(v2::k31_cols1024x4, v2::kLdsBytes + 64)
+  MI355_SET_LDS(v2::k31_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<4>, v2::kLdsBytes)
   return hipSuccess;
 }
 #undef MI355_SET_LDS
@@ -757,7 +742,12 @@ hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits
   return hipGetLastError();
 }
 hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s) {
-  hipLaunchKernelGGL(v2::k31_cols1024x4, dim3(pl.M2 / 8), dim3(512), v2::kLdsBytes + 64, s, pl, W, cw, flags, epoch, a, err);
+  const dim3 grid(pl.M2 / pl.C), block(512);
+  switch (pl.M1) {
+    case 512: hipLaunchKernelGGL(v2::k31_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, cw, flags, epoch, a, err); break;
+    case 1024: hipLaunchKernelGGL(v2::k31_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, cw, flags, epoch, a, err); break;
+    default: hipLaunchKernelGGL(v2::k31_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, cw, flags, epoch, a, err); break;
+  }
   return hipGetLastError();
 }
 
