@@ -84,6 +84,16 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   }
   for (int i = 0; i < 4; ++i) dp_.W5c[i] = pl_.W5c[i];
   { const char* tn = std::getenv("MI355_TUNE"); dp_.tune = tn ? uint32_t(std::atoi(tn)) : 0u; }
+  {
+    // the register-resident kernels keep two 512-thread work-groups per CU: a launch of more than one round
+    // boosts the groups of its last half round (kernels_v2.hip, boost_if_late)
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_));
+    const uint32_t slots = 2u * uint32_t(prop.multiProcessorCount);
+    auto from = [&](size_t grid) { return (!(dp_.tune & 4) && grid > slots) ? uint32_t(grid - slots / 2) : ~0u; };
+    dp_.boost_rows = from(pl_.M1);
+    dp_.boost_tiles = from(pl_.tiles());
+  }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
   {
     // kernel set: the register-resident radix-8 kernels where the shape is served, else the generic

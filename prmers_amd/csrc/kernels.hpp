@@ -15,7 +15,8 @@ struct DevPlan {
   uint64_t W5c[4];   // 5-point DFT constants {beta, k1, k2-k1, k1+k2} (kernels.hip dft5)
   const uint64_t *F0f, *F0i, *FBf, *FBi;   // four-step chain starts [tile][thread] and ratios [column] of the v2 column kernels
   const uint32_t* DI;   // digit-info words of the v2 column kernels: [tile][thread] 16 x (width - q, wrap), or null
-  uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs
+  uint32_t boost_rows, boost_tiles;   // first block index of the last half round of the row / column launches (or ~0u)
+  uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs; bit 2: no issue-priority boost of the last half round
 };
 
 hipError_t configure_kernels(size_t lds_front, size_t lds_mid);

@@ -123,6 +123,15 @@ __device__ __forceinline__ uint32_t tile_of_block(const DevPlan& pl, uint32_t b,
   if (!(pl.tune & 1) && (nblocks % 8 == 0)) return (b & 7) * (nblocks >> 3) + (b >> 3);
   return b;
 }
+// Issue-priority boost for the work-groups of the last half round.  Two work-groups share a CU and the older
+// one wins the issue arbitration, so at the end of a launch every CU is left with one late-started group
+// running alone at ~3/4 of the pair rate.  Raising the priority of exactly those late
+// groups (block index >= boost_from, set by the engine from the grid size and the CU count) lets them overtake
+// their older neighbour, and the two finish closer together: -3 % per squaring at C3 (same-box A/B).
+__device__ __forceinline__ void boost_if_late(uint32_t boost_from) {
+  if (blockIdx.x >= boost_from) __builtin_amdgcn_s_setprio(3);
+}
+
 // exchange helpers: barrier, write 8, barrier, read 8
 #define EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)                      \
   __syncthreads();                                                 \
@@ -153,6 +162,7 @@ template <int mode, int H>
 __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
                                                           uint64_t* __restrict__ Wout, uint32_t sub) {
   const uint32_t h = (H == 2) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0u;
+  if (H == 1) boost_if_late(pl.boost_rows);
   P2* X = reinterpret_cast<P2*>(smem_v2) + h * kLdsSlots;
   const uint32_t t = threadIdx.x & 511, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7), row = blockIdx.x;
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * (4096 * H);
@@ -256,6 +266,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
     for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[8 * k2];
   }
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
+  if (H == 1) __builtin_amdgcn_s_setprio(0);   // boosted groups: back to normal for the last stages (measured best drop point)
 #pragma unroll
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   dft8p<true>(x);
@@ -576,6 +587,7 @@ __global__ void __launch_bounds__(512, 4) k1_cols(DevPlan pl, const uint32_t* __
                                                   uint32_t sub, uint64_t* __restrict__ Wout) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = blockIdx.x;
+  boost_if_late(pl.boost_tiles);
   uint32_t dg[R][16 / R];
   const uint32_t di = pl.DI[size_t(T) * 512 + t];
 #pragma unroll
@@ -593,6 +605,7 @@ __global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __
                                                   uint64_t* __restrict__ cbuf, uint32_t a, uint64_t scale) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, blockIdx.x, gridDim.x);
+  boost_if_late(pl.boost_tiles);
   uint32_t dg[R][16 / R];
   uint64_t cout[R], zero[R];
 #pragma unroll
