@@ -90,7 +90,9 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_));
     const uint32_t slots = 2u * uint32_t(prop.multiProcessorCount);
-    auto from = [&](size_t grid) { return (!(dp_.tune & 4) && grid > slots) ? uint32_t(grid - slots / 2) : ~0u; };
+    const char* bf = std::getenv("MI355_BOOST");           // boosted part of the last round in percent (default 50)
+    const uint32_t pct = bf ? uint32_t(std::atoi(bf)) : 50u;
+    auto from = [&](size_t grid) { return (!(dp_.tune & 4) && grid > slots) ? uint32_t(grid - size_t(slots) * pct / 100) : ~0u; };
     dp_.boost_rows = from(pl_.M1);
     dp_.boost_tiles = from(pl_.tiles());
   }
