@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
                                                 uint64_t* __restrict__ Wout) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
+  if (blockIdx.x >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);   // last half round: see kernels_v2.hip, boost_if_late (C4: -2.7 %)
   const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
   const uint2* dg = reinterpret_cast<const uint2*>(digits) + size_t(T) * tile;
 
@@ -278,6 +279,7 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
                                               uint64_t* __restrict__ cbuf, uint32_t a) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
+  if (blockIdx.x >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);   // last half round: see kernels_v2.hip, boost_if_late (C4: -2.7 %)
   const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
   const P2* W = reinterpret_cast<const P2*>(Win);
 
