@@ -109,7 +109,9 @@ GF_HD uint64_t mul_u32(uint64_t a, uint32_t b) {
   return add(lo, s);  // lo may be >= P: see mul_pow2's note
 }
 
-// a * 2^s for 0 <= s < 192 (2 is a primitive 192nd root of unity, 2^96 = -1); a canonical.
+// a * 2^s for 0 <= s < 192 (2 is a primitive 192nd root of unity, 2^96 = -1); a may be any 64-bit
+// representative (s = 0 returns it unchanged, every other case returns a canonical value, or P for a negated zero
+// on the device).
 // With s a compile-time constant after inlining, or wave-uniform (scalar branches), this is a few
 // shifts and one or two modular add/sub -- a third to a half of a general mul().
 // add() below is called with a possibly non-canonical first operand (< 2^64) and a second operand
@@ -119,7 +121,7 @@ GF_HD uint64_t mul_pow2(uint64_t a, unsigned s) {
   if (s >= 96) { s -= 96; negate = true; }
   uint64_t r;
   if (s == 0) {
-    r = a;
+    r = negate ? fold(a) : a;   // the only case that passes the operand through: fold it before a negation
   } else if (s < 32) {
     // a*2^s = hi*2^64 + lo, hi < 2^32:  lo + hi*(2^32-1)
     const uint64_t lo = a << s, hi = a >> (64 - s);

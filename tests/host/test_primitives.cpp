@@ -30,5 +30,36 @@ int main(){
     gf::dft8<false>(f); gf::dft8<true>(g);
     for(int k=0;k<8;++k){ if (f[k]!=y[k]) { if(bad++<5) printf("dft8 fwd bad k=%d\n",k);} if (g[k]!=z[k]) { if(bad++<5) printf("dft8 inv bad k=%d\n",k);} }
   }
+  // lazy forms: add_lazy is congruent for every operand pair <= P (incl. the tail cases), fold brings any
+  // 64-bit representative back to [0, P), and the LAZY butterflies agree with the canonical ones after a fold;
+  // mul / mul_u32 / mul_pow2 accept any 64-bit representative (values in [P, 2^64) included)
+  {
+    const uint64_t P = gf::P;
+    const uint64_t edge[] = {0, 1, P - 1, P, P - 2, 0xffffffffull, 0xffffffff00000000ull, 0x8000000000000000ull, 0xfffffffefffffffeull};
+    for (uint64_t a : edge) for (uint64_t b : edge) {
+      const uint64_t l = gf::add_lazy(a, b);
+      if ((u128)l % P != ((u128)a + b) % P) { if (bad++<5) printf("add_lazy bad %llx %llx\n",(unsigned long long)a,(unsigned long long)b); }
+      if (gf::fold(l) != (uint64_t)(((u128)a + b) % P)) { if (bad++<5) printf("fold bad\n"); }
+      if (a <= P && b < P && gf::add(a, b) % P != (uint64_t)(((u128)a + b) % P)) { if (bad++<5) printf("add with P operand bad\n"); }
+      if (a <= P && b <= P && gf::sub(a, b) % P != (uint64_t)(((u128)a + P + P - b) % P)) { if (bad++<5) printf("sub with P operand bad\n"); }
+    }
+    const uint64_t tail[] = {P, P + 1, 0xffffffffffffffffull, 0xffffffff80000000ull};
+    for (uint64_t a : tail) {
+      for (unsigned s = 0; s < 192; ++s)
+        if (gf::mul_pow2(a, s) % P != ref_mul(a % P, gf::pow(2, s))) { if (bad++<5) printf("mul_pow2 non-canonical operand bad s=%u\n", s); }
+      if (gf::mul(a, 0x123456789abcdefull) != ref_mul(a % P, 0x123456789abcdefull)) { if (bad++<5) printf("mul non-canonical operand bad\n"); }
+    }
+    for (int it = 0; it < 500; ++it) {
+      uint64_t x[8], f0[8], f1[8], f2[8];
+      for (int j = 0; j < 8; ++j) { x[j] = ((((uint64_t)rand()<<42) ^ ((uint64_t)rand()<<21) ^ rand()) % P); if (it < 8 && j == it) x[j] = P - 1; f0[j] = f1[j] = f2[j] = x[j]; }
+      gf::dft8<false, 0>(f0); gf::dft8<false, 1>(f1); gf::dft8<true, 2>(f2);
+      uint64_t g0[8]; for (int j = 0; j < 8; ++j) g0[j] = x[j];
+      gf::dft8<true, 0>(g0);
+      for (int k = 0; k < 8; ++k) {
+        if (gf::fold(f1[k]) != f0[k]) { if (bad++<5) printf("dft8 LAZY=1 bad\n"); }
+        if (gf::fold(f2[k]) != g0[k]) { if (bad++<5) printf("dft8 LAZY=2 bad\n"); }
+      }
+    }
+  }
   printf(bad? "FAIL %d\n":"OK %d\n", bad); return bad!=0;
 }
