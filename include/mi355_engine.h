@@ -84,6 +84,9 @@ MI355_ENGINE_API int mi355_engine_time_square_mul(mi355_engine_handle handle, si
                                                   size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count);
 MI355_ENGINE_API size_t mi355_engine_kernel_count(mi355_engine_handle handle);
 MI355_ENGINE_API const char* mi355_engine_kernel_name(mi355_engine_handle handle, size_t k);
+/* device self-test of the GF(2^64-2^32+1) primitives (add, sub, mul, lazy forms, every power-of-two shift, the
+   radix-8 butterflies) against 128-bit host arithmetic; 1 = ok, 0 = mismatch or no device (see last_error) */
+MI355_ENGINE_API int mi355_engine_selftest(size_t device);
 /* algorithmic bytes one squaring moves (48 * n) */
 MI355_ENGINE_API size_t mi355_engine_algorithmic_bytes(mi355_engine_handle handle);
 

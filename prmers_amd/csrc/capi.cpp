@@ -7,6 +7,7 @@
 #include <string>
 
 #include "engine.hpp"
+namespace mi355 { void selftest_primitives(int device); }
 
 namespace {
 
@@ -110,6 +111,7 @@ int mi355_engine_time_square_mul(mi355_engine_handle h, size_t reg, uint32_t fac
 }
 size_t mi355_engine_kernel_count(mi355_engine_handle) { return mi355::Engine::kKernels; }
 const char* mi355_engine_kernel_name(mi355_engine_handle, size_t k) { return mi355::Engine::kernel_name(k); }
+int mi355_engine_selftest(size_t device) { return guarded([&] { mi355::selftest_primitives(int(device)); }); }
 size_t mi355_engine_algorithmic_bytes(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->algorithmic_bytes(); }); return r; }
 
 }  // extern "C"

@@ -68,6 +68,7 @@ def load_library():
         "mi355_engine_kernel_count": (sz, [vp]),
         "mi355_engine_kernel_name": (C.c_char_p, [vp, sz]),
         "mi355_engine_algorithmic_bytes": (sz, [vp]),
+        "mi355_engine_selftest": (C.c_int, [sz]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -85,7 +86,7 @@ EXPORTS = [
     "mi355_engine_set_digits", "mi355_engine_res64", "mi355_engine_register_data_size", "mi355_engine_get_data",
     "mi355_engine_set_data", "mi355_engine_checkpoint_size", "mi355_engine_get_checkpoint",
     "mi355_engine_set_checkpoint", "mi355_engine_time_square_mul", "mi355_engine_kernel_count",
-    "mi355_engine_kernel_name", "mi355_engine_algorithmic_bytes",
+    "mi355_engine_kernel_name", "mi355_engine_algorithmic_bytes", "mi355_engine_selftest",
 ]
 
 

@@ -403,3 +403,12 @@ def test_gmp_pins_at_baseline_exponents(p):
     from test_oracle_golden import check_pins
     with Engine(p, 2) as e:
         check_pins(e, p)
+
+
+def test_device_selftest_of_field_primitives():
+    """mi355_engine_selftest: the device code paths of gf.hpp / gfdft.hpp (borrow-reusing sub, P for a negated zero,
+    lazy sums, every shift of mul_pow2, the LAZY butterflies) against 128-bit host arithmetic on edge and random
+    operands, operands equal to P included."""
+    from prmers_amd.engine import load_library
+    L = load_library()
+    assert L.mi355_engine_selftest(0) == 1, L.mi355_engine_last_error().decode()

@@ -80,6 +80,16 @@ def _build_adapter(td):
     return exe
 
 
+def test_selftest_needs_a_device():
+    """without a GPU the device self-test reports failure through last_error instead of crashing"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from prmers_amd.engine import load_library
+    L = load_library()
+    assert L.mi355_engine_selftest(0) == 0 and L.mi355_engine_last_error()
+
+
 def test_cpp_adapter_builds_and_binds_every_symbol():
     """include/mi355/engine_hip.h compiles against the engine interface and dlsym-binds the C ABI."""
     from prmers_amd import engine as E
