@@ -488,7 +488,9 @@ void Engine::sub_u32(size_t r, uint32_t v) {
   if (v == 0) return;
   HIPCHK(hipSetDevice(device_));
   if (v2cols_ && uint64_t(pending_sub_[r]) + v < (1u << 30)) { pending_sub_[r] += v; return; }  // folded into the next front / middle sweep
-  normalize(r);
+  // the small subtraction only touches the digit vector (cyclic borrow), so run carries that are still pending
+  // for the next front sweep can stay pending: value = digits + carries - v either way
+  if (!(kind_[r] == kDigits && pl_.C >= 2 && !pending_sub_[r])) normalize(r);
   HIPCHK(launch_sub_small(dp_, digits(r), v, stream_));
 }
 
