@@ -339,6 +339,110 @@ def run_ll_safe(eng, p, block=0, erroriter=0, max_iters=None, log=None):
             "complete": it >= total}
 
 
+# register roles of the second LL-safe driver (RunLlSafeMarin.cpp:479): 18 registers
+(L2_RES_A, L2_RES_B, L2_ACC_A, L2_ACC_B, L2_CHK_A, L2_CHK_B, L2_SAVE_R_A, L2_SAVE_R_B, L2_SAVE_F_A, L2_SAVE_F_B,
+ L2_BASE_A, L2_BASE_B, L2_TA, L2_TB, L2_M0, L2_M1, L2_PREV_A, L2_PREV_B) = range(18)
+LLSAFE2_REGISTERS = 18
+
+
+def run_ll_safe2(eng, p, erroriter=0, checklevel=0, max_iters=None, log=None):
+    """Lucas-Lehmer in Z[sqrt 3] with the Gerbicz-Li check -- mirror of the reference's second LL-safe mode
+    (RunLlSafeMarin.cpp:394-728).  The residue is the pair (A, B) = A + B sqrt 3 = (2 + sqrt 3)^(2^k) mod 2^p-1,
+    squared p-1 times from (2, 1) (pair_square :481-490: A <- A^2 + 3 B^2, B <- 2 A B); every B = floor(sqrt p)
+    iterations the accumulator pair is multiplied by the residue (pair_mul_by :492-507) and every `checklevel`
+    blocks the Gerbicz-Li identity is verified on a copy and rolled back on a mismatch (:611-660).  2^p-1 is prime
+    iff the result is (-1, 0) (:664-671); the classic LL residue S_(p-2) = 2 A_(p-2) is reported (:674-680).
+    Needs 18 registers (`add` is the only operation beyond the PRP set)."""
+    log = log or (lambda m: None)
+    total = p - 1 if p > 1 else 0
+
+    def pair_square(A, Bq):
+        eng.copy(L2_TA, A); eng.copy(L2_TB, Bq)
+        eng.square_mul(A); eng.square_mul(Bq, 3); eng.add(A, Bq)
+        eng.copy(Bq, L2_TA)
+        eng.set_multiplicand(L2_M0, L2_TB)
+        eng.mul(Bq, L2_M0, 2)
+
+    def pair_mul_by(A, Bq, Cq, D):
+        eng.set_multiplicand(L2_M0, Cq); eng.set_multiplicand(L2_M1, D)
+        eng.copy(L2_TA, A); eng.copy(L2_TB, Bq)
+        eng.copy(A, L2_TA); eng.mul(A, L2_M0)
+        eng.copy(Bq, L2_TA); eng.mul(Bq, L2_M1)
+        eng.copy(L2_TA, L2_TB); eng.mul(L2_TA, L2_M1, 3); eng.add(A, L2_TA)
+        eng.copy(L2_TA, L2_TB); eng.mul(L2_TA, L2_M0); eng.add(Bq, L2_TA)
+
+    eng.set(L2_RES_A, 2); eng.set(L2_RES_B, 1)
+    eng.set(L2_ACC_A, 1); eng.set(L2_ACC_B, 0)
+    eng.copy(L2_SAVE_R_A, L2_RES_A); eng.copy(L2_SAVE_R_B, L2_RES_B)
+    eng.copy(L2_SAVE_F_A, L2_ACC_A); eng.copy(L2_SAVE_F_B, L2_ACC_B)
+    eng.set(L2_BASE_A, 2); eng.set(L2_BASE_B, 1)
+    eng.copy(L2_PREV_A, L2_RES_A); eng.copy(L2_PREV_B, L2_RES_B)
+
+    B = min(max(int(math.sqrt(p)), 1), max(total, 1))
+    auto = int((1000.0 * 600.0) / B)
+    if auto == 0:
+        auto = (total // B) // max(int(math.sqrt(B)), 1)
+    checkpasslevel = checklevel if checklevel > 0 else max(auto, 1)
+    itersave, jsave = 0, total - 1
+    checkpass = checks = errors = done = 0
+    errordone = False
+    it, j = 0, total - 1
+    while it < total:
+        if max_iters is not None and done >= max_iters:
+            break
+        if erroriter > 0 and it + 1 == erroriter and not errordone:
+            errordone = True
+            eng.sub(L2_RES_A, 2)
+            log("Injected error at iteration %d" % (it + 1))
+        if it + 1 == total:
+            eng.copy(L2_PREV_A, L2_RES_A); eng.copy(L2_PREV_B, L2_RES_B)
+        pair_square(L2_RES_A, L2_RES_B)
+        done += 1
+        if (j != 0 and j % B == 0) or it == total - 1:
+            checkpass += 1
+            eng.copy(L2_CHK_A, L2_ACC_A); eng.copy(L2_CHK_B, L2_ACC_B)
+            pair_mul_by(L2_ACC_A, L2_ACC_B, L2_RES_A, L2_RES_B)
+            if checkpass >= checkpasslevel or it == total - 1:
+                checks += 1
+                modB = B if total % B == 0 else total % B
+                for _ in range(B - modB - 1 if B > modB else 0):
+                    pair_square(L2_CHK_A, L2_CHK_B)
+                if modB != B:
+                    pair_square(L2_CHK_A, L2_CHK_B)
+                pair_mul_by(L2_CHK_A, L2_CHK_B, L2_BASE_A, L2_BASE_B)
+                for _ in range(modB):
+                    pair_square(L2_CHK_A, L2_CHK_B)
+                ok = eng.get_int(L2_CHK_A) == eng.get_int(L2_ACC_A) and eng.get_int(L2_CHK_B) == eng.get_int(L2_ACC_B)
+                if not ok:
+                    log("[Gerbicz-Li] Check FAILED at iter=%d block=[%d..%d]" % (it + 1, itersave + 1, it + 1))
+                    errors += 1
+                    eng.copy(L2_RES_A, L2_SAVE_R_A); eng.copy(L2_RES_B, L2_SAVE_R_B)
+                    eng.copy(L2_ACC_A, L2_SAVE_F_A); eng.copy(L2_ACC_B, L2_SAVE_F_B)
+                    checkpass = 0
+                    if itersave == 0:
+                        it, j = 0, jsave
+                    else:
+                        it, j = itersave + 1, jsave - 1
+                    log("[Gerbicz-Li] Restore iter=%d" % it)
+                    continue
+                log("[Gerbicz-Li] Check OK at iter=%d block=[%d..%d]" % (it + 1, itersave + 1, it + 1))
+                eng.copy(L2_SAVE_R_A, L2_RES_A); eng.copy(L2_SAVE_R_B, L2_RES_B)
+                eng.copy(L2_SAVE_F_A, L2_ACC_A); eng.copy(L2_SAVE_F_B, L2_ACC_B)
+                itersave, jsave = it, j
+                checkpass = 0
+        it += 1
+        j -= 1
+
+    Mp = (1 << p) - 1
+    complete = it >= total
+    is_prime = complete and eng.get_int(L2_RES_A) == Mp - 1 and eng.get_int(L2_RES_B) == 0
+    eng.add(L2_PREV_A, L2_PREV_A)          # S_(p-2) = 2 A_(p-2)
+    words = pack_words(eng.digits(L2_PREV_A), p)
+    return {"exponent": p, "mode": "llsafe2", "is_prime": bool(is_prime), "res64": format_res64(words),
+            "res2048": format_res2048(words), "iterations": it, "gerbicz_checks": checks, "gerbicz_errors": errors,
+            "complete": complete}
+
+
 def result_json(r, fft_length, program_version="mi355-marin-hip 0.1", port=8, user="", computer="", aid="", timestamp=""):
     """Result line in the reference's PrimeNet-style JSON (src/io/JsonBuilder.cpp:322-472): same keys, same
     order for the PRP / LL work types ("status" P/C, "worktype" PRP-3 / LL, res64, res2048 + residue-type 1

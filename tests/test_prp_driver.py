@@ -204,3 +204,39 @@ def test_ll_safe_detects_and_repairs_injected_error(kind, erroriter):
     assert r["is_prime"] and r["errors"] == 1 and r["res64"] == "0" * 16
     assert "Injected error at iteration %d" % erroriter in msgs
     assert "[Error check] Restore iter=%d" % blk_start in msgs
+
+
+def make_engine_n(kind, p, regs):
+    if kind == "gpu":
+        from prmers_amd import Engine
+        return Engine(p, regs)
+    return orc.OracleEngine(p, regs)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("p,prime", [(127, True), (521, True), (607, True), (1001, False), (1279, True)])
+def test_ll_safe2_pairs_with_gerbicz(kind, p, prime):
+    """second LL-safe mode (RunLlSafeMarin.cpp:394-728): (2 + sqrt 3)^(2^(p-1)) in pairs with the Gerbicz-Li check;
+    primality and the reported LL residue S_(p-2) against Python integers."""
+    msgs = []
+    with make_engine_n(kind, p, prp.LLSAFE2_REGISTERS) as e:
+        r = prp.run_ll_safe2(e, p, checklevel=1, log=msgs.append)
+    s, M = 4, (1 << p) - 1
+    for _ in range(p - 2):
+        s = (s * s - 2) % M
+    assert r["complete"] and r["is_prime"] == prime == (s == 0) and r["gerbicz_errors"] == 0 and r["gerbicz_checks"] >= 1
+    if prime:   # 0 may come out as the all-ones vector 2^p-1 (engine.h:286-295), as in the LL-unsafe mode
+        assert r["res64"] in ("0" * 16, "F" * 16)
+    else:
+        assert r["res64"] == "%016X" % (s & (2**64 - 1))
+    assert any(m.startswith("[Gerbicz-Li] Check OK") for m in msgs)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("erroriter", [1, 40, 700, 1278])
+def test_ll_safe2_detects_and_repairs_injected_error(kind, erroriter):
+    p, msgs = 1279, []
+    with make_engine_n(kind, p, prp.LLSAFE2_REGISTERS) as e:
+        r = prp.run_ll_safe2(e, p, erroriter=erroriter, checklevel=1, log=msgs.append)
+    assert r["is_prime"] and r["gerbicz_errors"] == 1 and r["res64"] in ("0" * 16, "F" * 16)
+    assert any("Check FAILED" in m for m in msgs) and any(m.startswith("[Gerbicz-Li] Restore iter=") for m in msgs)
