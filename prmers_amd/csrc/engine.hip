@@ -95,6 +95,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     auto from = [&](size_t grid) { return (!(dp_.tune & 4) && grid > slots) ? uint32_t(grid - size_t(slots) * pct / 100) : ~0u; };
     dp_.boost_rows = from(pl_.M1);
     dp_.boost_tiles = from(pl_.tiles());
+    dp_.boost_chain = from(2 * pl_.tiles());
   }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
   {
@@ -117,7 +118,8 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     // at 126 VGPRs and the sweeps are VALU-bound, so saving the digit round trip and one kernel boundary does
     // not pay; kept selectable with MI355_FUSED=1, off by default)
     const char* fz = std::getenv("MI355_FUSED");
-    fused_ = v2cols_ && fz && fz[0] == '1';
+    fused_ = v2cols_ && fz && (fz[0] == '1' || fz[0] == '2');
+    chained_ = fused_ && fz[0] == '2';   // back and front sweeps as two halves of one launch instead of one fused kernel
     if (fused_) {
       const size_t tiles = pl_.tiles();
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&cw_), tiles * pl_.M1 * 8));
@@ -405,7 +407,8 @@ void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
     run_middle(image(r), nullptr, image(r), 0, pending_sub_[r]);
     pending_sub_[r] = 0;
     if (ev) HIPCHK(hipEventRecord(ev[2], stream_));
-    HIPCHK(v2_launch_back_front(dp_, image(r), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
+    if (chained_) HIPCHK(v2_launch_back_then_front(dp_, image(r), reinterpret_cast<uint32_t*>(work()), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
+    else HIPCHK(v2_launch_back_front(dp_, image(r), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
     if (ev) { HIPCHK(hipEventRecord(ev[3], stream_)); HIPCHK(hipEventRecord(ev[4], stream_)); }
     return;
   }
@@ -459,7 +462,8 @@ void Engine::mul(size_t dst, size_t src, uint32_t a) {
     ensure_front(dst);
     run_middle(image(dst), image(src), image(dst), 1, pending_sub_[dst]);
     pending_sub_[dst] = 0;
-    HIPCHK(v2_launch_back_front(dp_, image(dst), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
+    if (chained_) HIPCHK(v2_launch_back_then_front(dp_, image(dst), reinterpret_cast<uint32_t*>(work()), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
+    else HIPCHK(v2_launch_back_front(dp_, image(dst), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
     return;
   }
   run_front(dst);

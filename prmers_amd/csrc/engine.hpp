@@ -89,7 +89,7 @@ class Engine {
   uint64_t* cw_ = nullptr;                    // fused sweep: carry words between work-groups
   uint32_t* flags_ = nullptr;                 // fused sweep: per-work-group epoch flags (+ error word at the end)
   uint32_t epoch_ = 0;
-  bool fused_ = false;
+  bool fused_ = false, chained_ = false;
   uint64_t* cbuf_ = nullptr;
   void* tables_ = nullptr;
   uint64_t* f0_ = nullptr;   // four-step chain starts / ratios of the register-resident column kernels

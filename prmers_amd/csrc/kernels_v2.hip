@@ -674,6 +674,99 @@ __global__ void __launch_bounds__(512, 4) k31_cols(DevPlan pl, uint64_t* __restr
 }  // namespace v2
 
 namespace v2 {
+// Agent-coherent (write-through / cache-bypassing) 16-byte accesses for in-launch hand-offs, per
+// cdna_hip_programming.md Guideline 16 R1: aux = 16 is the sc1 bit on gfx950.
+typedef int hx_v4i __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t hx_rsrc_t;
+__device__ __forceinline__ hx_rsrc_t hx_rsrc(void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, /*stride*/ 0, int(bytes), 0x00020000);
+}
+__device__ __forceinline__ void hx_store16_sc1(hx_rsrc_t rsrc, uint32_t byte_off, uint4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(hx_v4i{int(v.x), int(v.y), int(v.z), int(v.w)}, rsrc, int(byte_off), 0, 16);
+}
+__device__ __forceinline__ uint4 hx_load16_sc1(hx_rsrc_t rsrc, uint32_t byte_off) {
+  const hx_v4i r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(byte_off), 0, 16);
+  return make_uint4(uint32_t(r.x), uint32_t(r.y), uint32_t(r.z), uint32_t(r.w));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chained back -> front sweep in ONE launch (experimental, MI355_FUSED=2): blocks [0, NT) are the back sweep of
+// tile tile_of_block(b) (work buffer -> digits in a scratch area + carry words), blocks [NT, 2 NT) the front
+// sweep of tile tile_of_block(b - NT) (scratch digits + carry-in -> work buffer, in place).  A front block
+// waits for the flags of its own tile and of the previous one; both belong to back blocks, and every back
+// block has been dispatched before the first front block is (one launch, in-order dispatch), so the wait
+// always resolves.  Unlike the fused kernel above the two halves keep their own register budgets and the
+// front blocks fill the drain of the back ones.  Hand-off (cdna_hip_programming.md Guideline 16 R1): sc1
+// (write-through) stores of the digits and carry words -> every wave drains its stores -> barrier -> flag;
+// the consumer polls the flags, then reads the handed-off words with sc1 loads only.
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(512, 4) k3k1_cols(DevPlan pl, uint64_t* __restrict__ Wbuf, uint32_t* __restrict__ scratch,
+                                                    uint64_t* __restrict__ cw, uint32_t* __restrict__ flags, uint32_t epoch, uint32_t a,
+                                                    uint32_t* __restrict__ err) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t NT = gridDim.x >> 1;
+  constexpr uint32_t M1 = 512 * R;
+  uint32_t dg[R][16 / R];
+  if (blockIdx.x < NT) {   // ---- back sweep of one tile ----
+    const uint32_t T = tile_of_block(pl, blockIdx.x, NT);
+    const uint32_t di = pl.DI[size_t(T) * 512 + t];
+    uint64_t cout[R], zero[R];
+#pragma unroll
+    for (int d1 = 0; d1 < R; ++d1) zero[d1] = 0;
+    back_tile<R>(pl, X, T, t, lane, wave, Wbuf, a, 1, zero, di, dg, cout);
+    // write-through (sc1) stores of the handed-off digits and carry words: no release fence needed
+    const hx_rsrc_t rs = hx_rsrc(scratch, pl.n * 4u);
+    constexpr int Q = 4 / R;   // uint4 per run
+#pragma unroll
+    for (int d1 = 0; d1 < R; ++d1) {
+      const uint32_t i1 = 512 * d1 + t;
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        hx_store16_sc1(rs, uint32_t(((size_t(T) * M1 + i1) * Q + q) * 16), make_uint4(dg[d1][4 * q], dg[d1][4 * q + 1], dg[d1][4 * q + 2], dg[d1][4 * q + 3]));
+      __hip_atomic_store(cw + size_t(T) * M1 + i1, cout[d1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(flags + T, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- front sweep of one tile ----
+  const uint32_t bf = blockIdx.x - NT;
+  const uint32_t T = tile_of_block(pl, bf, NT), pT = T ? T - 1 : NT - 1;
+  if (blockIdx.x >= pl.boost_chain) __builtin_amdgcn_s_setprio(3);
+  if (t == 0) {
+    uint32_t ok = 0;
+    for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+      if (__hip_atomic_load(flags + T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
+          __hip_atomic_load(flags + pT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) atomicOr(err, 1u);
+  }
+  __syncthreads();
+  const uint32_t di = pl.DI[size_t(T) * 512 + t];
+  const hx_rsrc_t rs = hx_rsrc(scratch, pl.n * 4u);
+  constexpr int Q = 4 / R;
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) {
+    const uint32_t i1 = 512 * d1 + t;
+    const uint32_t pi = T ? i1 : (i1 ? i1 - 1 : M1 - 1);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {   // every load of handed-off data is sc1 (cache-bypassing)
+      const uint4 v = hx_load16_sc1(rs, uint32_t(((size_t(T) * M1 + i1) * Q + q) * 16));
+      dg[d1][4 * q] = v.x; dg[d1][4 * q + 1] = v.y; dg[d1][4 * q + 2] = v.z; dg[d1][4 * q + 3] = v.w;
+    }
+    const uint64_t cin = __hip_atomic_load(cw + size_t(pT) * M1 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    apply_carry_in<16 / R>(pl, di, d1, cin, dg[d1]);
+  }
+  front_tile<R>(pl, X, T, t, lane, wave, dg, di, 0, Wbuf);
+}
+
+}  // namespace v2
+
+namespace v2 {
 // chain starts and ratios of the four-step twiddle chains of the column kernels (same thread map as the last
 // stage of front_tile / first stage of back_tile): F0f[T][t] = omega_m^(i2 kb) TB[2 i2], F0i the inverse with
 // TBi, FBf[i2] = omega_m^(64R i2), FBi its inverse.
@@ -722,6 +815,7 @@ hipError_t v2_configure() {
   MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes)
   MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
+  MI355_SET_LDS(v2::k3k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k31_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<4>, v2::kLdsBytes)
   return hipSuccess;
 }
@@ -751,6 +845,16 @@ hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits
     case 512: hipLaunchKernelGGL(v2::k3_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
     case 1024: hipLaunchKernelGGL(v2::k3_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
     default: hipLaunchKernelGGL(v2::k3_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
+  }
+  return hipGetLastError();
+}
+hipError_t v2_launch_back_then_front(const DevPlan& pl, uint64_t* W, uint32_t* scratch, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a,
+                                     uint32_t* err, hipStream_t s) {
+  const dim3 grid(2 * (pl.M2 / pl.C)), block(512);
+  switch (pl.M1) {
+    case 512: hipLaunchKernelGGL(v2::k3k1_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, scratch, cw, flags, epoch, a, err); break;
+    case 1024: hipLaunchKernelGGL(v2::k3k1_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, scratch, cw, flags, epoch, a, err); break;
+    default: hipLaunchKernelGGL(v2::k3k1_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, scratch, cw, flags, epoch, a, err); break;
   }
   return hipGetLastError();
 }

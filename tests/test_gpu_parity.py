@@ -369,11 +369,13 @@ def test_register_resident_columns_other_shapes_full_size(p, n, m1):
         assert e.res64(0) == o.res64(0)
 
 
+@pytest.mark.parametrize("fused", ["1", "2"])
 @pytest.mark.parametrize("p,plan", [(300007, "m2=8,c=4"), (300007, "m2=16,c=8"), (600011, "m2=8,c=2"), (136279841, None), (57885161, None)])
-def test_fused_back_front_sweep(p, plan, monkeypatch):
-    """MI355_FUSED=1: the residue stays a front image between squarings (inter-work-group carry hand-off);
-    every engine operation must still agree with the oracle."""
-    monkeypatch.setenv("MI355_FUSED", "1")
+def test_fused_back_front_sweep(p, plan, fused, monkeypatch):
+    """MI355_FUSED=1 (one fused kernel per tile) and =2 (back and front blocks chained in one launch): the
+    residue stays a front image between squarings (inter-work-group hand-off through flags); every engine
+    operation must still agree with the oracle."""
+    monkeypatch.setenv("MI355_FUSED", fused)
     o = orc.Oracle(p, 4)
     rng = np.random.default_rng(p)
     w = o.widths().astype(np.uint64)
