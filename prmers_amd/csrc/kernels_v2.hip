@@ -107,13 +107,6 @@ __device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
   return gf::mul(lo, hi);
 }
 
-__device__ __forceinline__ void digit_info(const DevPlan& pl, uint32_t sa, uint32_t sb, uint32_t& width, bool& wrap) {
-  uint32_t s = sa + sb;   // sa, sb < n <= 5*2^23: 32-bit arithmetic suffices
-  wrap = (sa > 0) && (sb > 0) && (s <= pl.n);
-  if (s >= pl.n) s -= pl.n;
-  width = pl.q + ((s + pl.t > 0) ? 1u : 0u) + ((s + pl.t > pl.n) ? 1u : 0u) - ((s > 0) ? 1u : 0u);
-}
-
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_v2[];
 
 // block -> tile for the back sweep: blocks that share an XCD (b, b+8, ... under round-robin dispatch)
