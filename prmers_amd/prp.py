@@ -167,13 +167,18 @@ def shard_worktodo(lines, rank, world):
 # the driver
 # ---------------------------------------------------------------------------------------------
 def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, max_iters=None,
-                  log=None, ckpt_path=None, backup_every=0):
+                  log=None, ckpt_path=None, backup_every=0, resume=None, stop_after_s=None):
     """One PRP (mode "prp") or LL-unsafe (mode "ll") test of 2^p-1 on `eng` (>= 8 registers).
 
     Returns a dict: is_prime, res64, res2048, iterations, gerbicz_checks, gerbicz_errors, complete.
     max_iters stops early (complete = False) for partial runs; the result fields then describe the
     residue reached.  log(msg) receives the reference's messages ("[Gerbicz Li] Check passed! iter=N").
+    resume = {"it": i, "j": j}: continue a PRP right after the passed Gerbicz-Li check of iteration i (the
+    caller has put the residue into R0 and the Gerbicz accumulator into R1); stop_after_s: stop at the first
+    passed check after that many seconds and return that state in result["state"] (long runs in slices).
     """
+    import time as _time
+    t_start = _time.time()
     log = log or (lambda m: None)
     prp = mode == "prp"
     total = p if prp else p - 2
@@ -183,7 +188,7 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
         if got:
             ri = got[0]
             log("Resuming from a checkpoint.")
-    if ri == 0:
+    if ri == 0 and resume is None:
         eng.set(R1, 1)
         eng.set(R0, 3 if prp else 4)
     eng.copy(R4, R0)          # last state that passed a check
@@ -202,8 +207,14 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     checks = errors = 0
     done = 0
     it, j = ri, total - ri - 1
+    if resume is not None:
+        itersave, jsave = int(resume["it"]), int(resume["j"])
+        it, j = itersave + 1, jsave - 1
+    state = None
     while it < total:
         if max_iters is not None and done >= max_iters:
+            break
+        if state is not None:
             break
         eng.square_mul(R0)
         if not prp:
@@ -246,6 +257,8 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
                     eng.copy(R4, R0)
                     eng.copy(R5, R1)
                     itersave, jsave = it, j
+                    if stop_after_s is not None and _time.time() - t_start > stop_after_s and it != total - 1:
+                        state = {"it": it, "j": j}
         if ckpt_path and backup_every and done % backup_every == 0:
             save_checkpoint(ckpt_path, eng, p, mode, it + 1, 0.0)
         it += 1
@@ -261,7 +274,7 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
         words = prp3_div9(p, words)
     return {"exponent": p, "mode": mode, "is_prime": bool(is_prime) and it >= total, "res64": format_res64(words),
             "res2048": format_res2048(words), "iterations": it, "gerbicz_checks": checks,
-            "gerbicz_errors": errors, "complete": it >= total}
+            "gerbicz_errors": errors, "complete": it >= total, "state": state}
 
 
 # register roles of the LL-safe driver (RunLlSafeMarin.cpp:20-28: V, U, their last good copies, the re-run copies)

@@ -240,3 +240,21 @@ def test_ll_safe2_detects_and_repairs_injected_error(kind, erroriter):
         r = prp.run_ll_safe2(e, p, erroriter=erroriter, checklevel=1, log=msgs.append)
     assert r["is_prime"] and r["gerbicz_errors"] == 1 and r["res64"] in ("0" * 16, "F" * 16)
     assert any("Check FAILED" in m for m in msgs) and any(m.startswith("[Gerbicz-Li] Restore iter=") for m in msgs)
+
+
+def test_prp_in_slices_resumes_after_a_passed_check():
+    """run_prp_or_ll(resume=..., stop_after_s=...): a PRP of M9941 cut into three slices, each continued on a
+    fresh engine from (residue, Gerbicz accumulator, iteration) saved right after a passed check, ends on the
+    same answer as an uninterrupted run (tools/long_prp.py uses this for runs longer than one GPU-box call)."""
+    p = 9941
+    state, saved = None, None
+    for slice_no in range(3):
+        with orc.OracleEngine(p, prp.REGISTERS) as e:
+            if state is not None:
+                e.o.set_digits(prp.R0, saved[0]); e.o.set_digits(prp.R1, saved[1])
+            r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, resume=state, stop_after_s=None if slice_no == 2 else 0.0)
+            if slice_no < 2:
+                assert r["state"] is not None and not r["complete"] and r["gerbicz_errors"] == 0
+                state, saved = r["state"], (e.digits(prp.R0), e.digits(prp.R1))
+    assert r["complete"] and r["is_prime"] and r["res64"] == "0000000000000001" and r["gerbicz_errors"] == 0
+    assert state["it"] > 100   # the third slice really started in the middle
