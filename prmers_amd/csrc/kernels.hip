@@ -278,7 +278,10 @@ __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __r
 __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
                                               uint64_t* __restrict__ cbuf, uint32_t a) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  // blocks that share an XCD (b, b + 8, ...) take neighbouring tiles: the 64-byte pieces of a work-buffer line meet in one L2
+  // (same order as the register-resident back sweep; C4: 93.3 -> 90.4 us).  MI355_TUNE bit 0 switches it off.
+  const uint32_t T = (!(pl.tune & 1) && gridDim.x % 8 == 0) ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   if (blockIdx.x >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);   // last half round: see kernels_v2.hip, boost_if_late (C4: -2.7 %)
   const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
   const P2* W = reinterpret_cast<const P2*>(Win);
