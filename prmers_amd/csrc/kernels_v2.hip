@@ -190,9 +190,9 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   uint64_t sw[8];   // seam twiddles: loaded before the exchange so that their latency hides behind it
   {
     const uint32_t k1 = t & 7, b = t >> 3;
-    const uint64_t* __restrict__ tw = pl.S2r + b * 64 + k1;
+    const uint64_t* __restrict__ tw = pl.S2r + b * 64 + k1 * 8;   // [b][k1][k2]: 64 contiguous bytes per thread
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[8 * k2];
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[k2];
   }
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false, 2>(x);   // all outputs are multiplied next
@@ -254,9 +254,9 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   dft8p<true, 2>(x);   // exchanged, then multiplied by the seam twiddles
   {
     const uint32_t k1 = t & 7, b = t >> 3;
-    const uint64_t* __restrict__ tw = pl.S2ri + b * 64 + k1;
+    const uint64_t* __restrict__ tw = pl.S2ri + b * 64 + k1 * 8;   // [b][k1][k2]: 64 contiguous bytes per thread
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[8 * k2];
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[k2];
   }
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
   if (H == 1) __builtin_amdgcn_s_setprio(0);   // boosted groups: back to normal for the last stages (measured best drop point)
@@ -426,9 +426,9 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   uint64_t sw[8];   // seam twiddles, requested before the exchange that hides their latency
   {
     const uint32_t k1 = (t & 7) >> LC, b = t >> 3;
-    const uint64_t* __restrict__ tw = pl.S1r + b * (8 * R) + k1;
+    const uint64_t* __restrict__ tw = pl.S1r + b * (8 * R) + k1 * 8;   // [b][k1][k2]
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[R * k2];
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[k2];
   }
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false, 2>(x);
@@ -513,9 +513,9 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   uint64_t sw[8];
   {
     const uint32_t k1 = (t & 7) >> LC, b = t >> 3;
-    const uint64_t* __restrict__ tw = pl.S1ri + b * (8 * R) + k1;
+    const uint64_t* __restrict__ tw = pl.S1ri + b * (8 * R) + k1 * 8;   // [b][k1][k2]
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[R * k2];
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[k2];
   }
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
 #pragma unroll

@@ -62,7 +62,7 @@ struct Plan {
   std::vector<uint64_t> TA, TAi, TB, TBi;  // 2^(1/n) powers; TAi carries the 1/m factor
   std::vector<uint64_t> TWlo, TWhi;      // two-level omega_m table
   std::vector<uint64_t> UT1, UT2;        // omega_M1^e (e < M1), omega_M2^e (e < M2)
-  // seam twiddles of the radix-8 kernels, laid out [b][ka] so that a wave reads runs of consecutive entries:
+  // seam twiddles of the radix-8 kernels, laid out [b][k1][k2] so that a thread's 8 words are contiguous (64 B):
   // S2r[b*64+ka] = omega_4096^(ka*b) (rows of 4096 = 64 x 64), S1r[b*(M1/64)+ka] = omega_M1^(ka*b) (columns M1 = 512/1024/2048 = (M1/64) x 64); *i = inverses
   std::vector<uint64_t> S2r, S2ri, S1r, S1ri;
   // register-resident column kernels: one word per (tile, thread) with 2 bits per digit of the thread's 16
@@ -199,7 +199,8 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
     pl.S2r.resize(4096); pl.S2ri.resize(4096);
     for (uint32_t b = 0; b < 64; ++b) for (uint32_t ka = 0; ka < 64; ++ka) {
       const uint32_t e = ka * b;
-      pl.S2r[b * 64 + ka] = pl.UT2[st * e]; pl.S2ri[b * 64 + ka] = pl.UT2[st * ((4096 - e) & 4095)];
+      const uint32_t idx = b * 64 + (ka & 7) * 8 + (ka >> 3);   // [b][k1][k2], ka = k1 + 8 k2: a thread's 8 words are contiguous
+      pl.S2r[idx] = pl.UT2[st * e]; pl.S2ri[idx] = pl.UT2[st * ((4096 - e) & 4095)];
     }
   }
   if (pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048)) {   // M1 = 512 R = (8R) x 64
@@ -207,7 +208,8 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
     pl.S1r.resize(pl.M1); pl.S1ri.resize(pl.M1);
     for (uint32_t b = 0; b < 64; ++b) for (uint32_t ka = 0; ka < ka_n; ++ka) {
       const uint32_t e = ka * b;
-      pl.S1r[b * ka_n + ka] = pl.UT1[e]; pl.S1ri[b * ka_n + ka] = pl.UT1[(pl.M1 - e) & (pl.M1 - 1)];
+      const uint32_t Rr = pl.M1 / 512, idx = b * ka_n + (ka % Rr) * 8 + (ka / Rr);   // [b][k1][k2], ka = k1 + R k2
+      pl.S1r[idx] = pl.UT1[e]; pl.S1ri[idx] = pl.UT1[(pl.M1 - e) & (pl.M1 - 1)];
     }
   }
   if (m % 4 == 0) { pl.I4 = gf::pow(om, m / 4); pl.I4inv = gf::inv(pl.I4); }
