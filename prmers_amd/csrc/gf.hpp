@@ -2,6 +2,13 @@
 //
 // Written from scratch for CDNA4: there is no 64x64->128 multiplier on the VALU, so mul() is
 // four 32x32+64 multiply-adds (v_mad_u64_u32) followed by the 2^64 = 2^32-1, 2^96 = -1 folding.
+// Device forms (round 2, measured in profiles/r02_microbench_gf.txt): the VALU issues VOP1/VOP2 adds, logic
+// and selects at one wave-instruction per ~2.7 cycles and everything else (carry forms, compares, VOP3
+// encodings, 64-bit shifts) per ~4.5-5.2, so the reductions below (a) let v_mad_u64_u32 do the "x + h (2^32-1)"
+// addition and hand its carry-out to the correction as a lane mask, (b) keep the select masks in VCC with the
+// selected constant in a VGPR (VOP2 v_cndmask_b32), (c) apply "- (2^32-1)" as one signed multiply-add
+// (65535 * -65537), and (d) send the two corrections of a product that almost never occur (probability
+// ~2^-32 per lane) through a wave-uniform branch instead of computing their masks every time.
 // Field definition follows the reference (include/marin/arith.h:24-72, kernels/marin.cl:112-148):
 // same prime, same generator 7, sqrt(-1) = 2^48.  Everything here is canonical (inputs and
 // outputs in [0, P)) unless a function says "lazy".
@@ -20,23 +27,130 @@ namespace gf {
 constexpr uint64_t P = 0xffffffff00000001ull;
 constexpr uint64_t EPS = 0xffffffffull;  // 2^64 mod P = 2^32 - 1
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GF_PORTABLE_DEVICE)
+#define GF_ASM 1
+namespace dev {
+// Per-thread constants behind an opaque asm (no inputs: the copies within a kernel are merged and hoisted), so
+// that "mask ? c : 0" stays a VOP2 v_cndmask_b32 with a VGPR operand instead of a VOP3 one with literals.
+__device__ __forceinline__ uint32_t k_ones() { uint32_t r; asm("v_mov_b32 %0, -1" : "=v"(r)); return r; }
+__device__ __forceinline__ uint32_t k_ffff() { uint32_t r; asm("v_mov_b32 %0, 0xffff" : "=v"(r)); return r; }
+constexpr uint64_t PM1 = 0xffffffff00000000ull;   // P - 1
+
+// d - (v ? 2^32-1 : 0) for v in {0, 65535}:  d + v * -65537 (one v_mad_i64_i32)
+// The unused carry-out goes to a fixed scalar pair that nothing ever reads: an allocated one could be rewritten by a
+// scalar instruction and read by a vector one right after this statement, inside the two wait states the compiler
+// keeps after VALU writes of an SGPR that it can see (it cannot see into asm).
+__device__ __forceinline__ uint64_t sub_eps_if(uint64_t d, uint32_t v) {
+  uint64_t r;
+  asm("v_mad_i64_i32 %0, s[94:95], %1, %2, %3" : "=v"(r) : "v"(v), "s"(int32_t(-65537)), "v"(d) : "s94", "s95");
+  return r;
+}
+// x*y + z, carry out as a lane mask
+__device__ __forceinline__ uint64_t mad_c(uint32_t x, uint32_t y, uint64_t z, uint64_t& cy) {
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cy) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+// x + h (2^32-1) for x + h (2^32-1) < 2^64 + (2^32-1)^2:  canonical.  A carry means "+ 2^64 == + EPS" and leaves
+// r < h EPS, so the addition of EPS cannot carry again; without a carry r >= P is folded the same way.
+__device__ __forceinline__ uint64_t mad_eps_fold(uint32_t h, uint64_t x) {
+  uint64_t r, t;
+  uint32_t m;
+  asm("v_mad_u64_u32 %0, vcc, %3, -1, %4\n\t"
+      "v_cmp_lt_u64 %1, %5, %0\n\t"
+      "s_or_b64 vcc, vcc, %1\n\t"
+      "v_cndmask_b32_e32 %2, 0, %6, vcc"
+      : "=&v"(r), "=&s"(t), "=&v"(m)
+      : "v"(h), "v"(x), "s"(PM1), "v"(k_ones())
+      : "vcc", "scc");   // s_or_b64 writes SCC
+  return r + uint64_t(m);
+}
+// lo - hh - cin (cin: lane mask), borrow out as a lane mask
+__device__ __forceinline__ uint64_t sub32_c(uint64_t lo, uint32_t hh, uint64_t cin, uint64_t& bw) {
+  uint32_t r0, r1;
+  asm("v_subb_co_u32 %0, vcc, %3, %4, %5\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %1, %2, 0, %6, vcc"
+      : "=&v"(r0), "=v"(r1), "=s"(bw)
+      : "v"(uint32_t(lo)), "v"(hh), "s"(cin), "v"(uint32_t(lo >> 32))
+      : "vcc");
+  return (uint64_t(r1) << 32) | r0;
+}
+// x + hl (2^32-1), canonical, where x = lo - hh - cin was formed with borrow mask bw (sub32_c):
+//   bw = 0: x exact;           carry -> + EPS (every other product);  r >= P without carry -> + EPS   (rare)
+//   bw = 1: x = true + 2^64;   carry -> exact;                        no carry -> - EPS               (rare)
+// bw itself needs lo < 2^32 and so is rare: the fast path is "carry -> + EPS" with one test that no lane has
+// bw or r >= P; the slow path applies +-EPS = 65535 * +-65537 to the lanes that need it.
+__device__ __forceinline__ uint64_t reduce_tail(uint32_t hl, uint64_t x, uint64_t bw) {
+  uint64_t r, t;
+  uint32_t m, k;
+  asm("v_mad_u64_u32 %0, vcc, %4, -1, %5\n\t"
+      "v_cmp_lt_u64 %1, %7, %0\n\t"
+      "s_or_b64 %1, %1, %6\n\t"            // r >= P, or borrowed
+      "s_and_b64 %1, %1, exec\n\t"
+      "s_cbranch_scc0 .Lgf_fast%=\n\t"
+      "s_andn2_b64 %1, %1, vcc\n\t"        // ... and no carry: the lanes that change (with bw: -EPS, without: +EPS)
+      "v_mov_b32 %2, 0x10001\n\t"
+      "v_mov_b32 %3, 0xfffeffff\n\t"
+      "v_cndmask_b32 %2, %2, %3, %6\n\t"   // 65537 or -65537
+      "v_mov_b32 %3, 0xffff\n\t"
+      "v_cndmask_b32 %3, 0, %3, %1\n\t"
+      "v_mad_i64_i32 %0, %1, %3, %2, %0\n\t"
+      "s_andn2_b64 vcc, vcc, %6\n"          // a borrowed lane that carried is exact
+      ".Lgf_fast%=:\n\t"
+      "v_cndmask_b32_e32 %2, 0, %8, vcc"
+      : "=&v"(r), "=&s"(t), "=&v"(m), "=&v"(k)
+      : "v"(hl), "v"(x), "s"(bw), "s"(PM1), "v"(k_ones())
+      : "vcc", "scc");
+  return r + uint64_t(m);
+}
+}  // namespace dev
+#endif
+
 GF_HD uint64_t add(uint64_t a, uint64_t b) {
+#if defined(GF_ASM)
+  unsigned c0, c1;
+  const uint32_t lo = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c0);
+  const uint32_t hi = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c0, &c1);
+  const uint64_t s = ((uint64_t)hi << 32) | lo;
+  const uint32_t ones = dev::k_ones();
+  const uint32_t m = ((c1 != 0) | (s >= P)) ? ones : 0u;
+  return s + m;
+#else
   uint64_t s = a + b;
   // true sum < 2P.  Subtract P (== add EPS mod 2^64) when the 65-bit sum is >= P.
   bool ge = (s < a) | (s >= P);
   return s + (ge ? EPS : 0ull);
+#endif
 }
 
 // a + b without the final ">= P" fold: the result is congruent to a + b but may lie anywhere in [0, 2^64).
 // For operands <= P the single carry fold cannot overflow again (a + b - 2^64 + EPS < 2^64).  Only for
 // values whose next use is a multiplication (mul, mul_u32, mul_pow2 accept any 64-bit operand).
 GF_HD uint64_t add_lazy(uint64_t a, uint64_t b) {
+#if defined(GF_ASM)
+  unsigned c0, c1;
+  const uint32_t lo = __builtin_addc((uint32_t)a, (uint32_t)b, 0u, &c0);
+  const uint32_t hi = __builtin_addc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c0, &c1);
+  const uint32_t ones = dev::k_ones();
+  const uint32_t m = c1 ? ones : 0u;
+  return (((uint64_t)hi << 32) | lo) + m;
+#else
   uint64_t s = a + b;
   return s + ((s < a) ? EPS : 0ull);
+#endif
 }
 
 // any 64-bit representative -> [0, P)
-GF_HD uint64_t fold(uint64_t a) { return a + ((a >= P) ? EPS : 0ull); }
+GF_HD uint64_t fold(uint64_t a) {
+#if defined(GF_ASM)
+  const uint32_t ones = dev::k_ones();
+  const uint32_t m = (a >= P) ? ones : 0u;
+  return a + m;
+#else
+  return a + ((a >= P) ? EPS : 0ull);
+#endif
+}
 
 GF_HD uint64_t sub(uint64_t a, uint64_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -46,7 +160,12 @@ GF_HD uint64_t sub(uint64_t a, uint64_t b) {
   uint32_t lo = __builtin_subc((uint32_t)a, (uint32_t)b, 0u, &c0);
   uint32_t hi = __builtin_subc((uint32_t)(a >> 32), (uint32_t)(b >> 32), c0, &c1);
   uint64_t d = ((uint64_t)hi << 32) | lo;
+#if defined(GF_ASM)
+  const uint32_t kf = dev::k_ffff();
+  return dev::sub_eps_if(d, c1 ? kf : 0u);   // d + P == d - EPS (mod 2^64)
+#else
   return d + (c1 ? P : 0ull);
+#endif
 #else
   uint64_t d = a - b;
   return d - ((a < b) ? EPS : 0ull);
@@ -90,9 +209,23 @@ GF_HD void mul64x64(uint64_t a, uint64_t b, uint64_t& lo, uint64_t& hi) {
 }
 
 GF_HD uint64_t mul(uint64_t a, uint64_t b) {
+#if defined(GF_ASM)
+  const uint32_t a0 = uint32_t(a), a1 = uint32_t(a >> 32), b0 = uint32_t(b), b1 = uint32_t(b >> 32);
+  const uint64_t t0 = uint64_t(a0) * b0;
+  const uint64_t t1 = uint64_t(a0) * b1 + (t0 >> 32);
+  uint64_t c, bw;
+  const uint64_t t2 = dev::mad_c(a1, b0, t1, c);            // the carry c has weight 2^96: the product's high half is t3 + c 2^32
+  const uint64_t t3 = uint64_t(a1) * b1 + (t2 >> 32);
+  const uint64_t lo = (t2 << 32) | uint32_t(t0);
+  // lo + hl EPS - hh - c.  The two instructions that form t3 separate the write of c from its read below
+  // (gfx950 needs two wait states between a VALU write of an SGPR and a VALU read; tools/check_isa_hazards.py).
+  const uint64_t x = dev::sub32_c(lo, uint32_t(t3 >> 32), c, bw);
+  return dev::reduce_tail(uint32_t(t3), x, bw);
+#else
   uint64_t lo, hi;
   mul64x64(a, b, lo, hi);
   return reduce128(lo, hi);
+#endif
 }
 
 GF_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
@@ -105,8 +238,12 @@ GF_HD uint64_t mul_u32(uint64_t a, uint32_t b) {
   uint64_t lo = (t1 << 32) | (uint32_t)t0;
   uint64_t hi = t1 >> 32;  // < 2^32: hh = 0
   // lo + hi*(2^32-1)
+#if defined(GF_ASM)
+  return dev::mad_eps_fold(uint32_t(hi), lo);
+#else
   uint64_t s = (hi << 32) - hi;  // < P
   return add(lo, s);  // lo may be >= P: see mul_pow2's note
+#endif
 }
 
 // a * 2^s for 0 <= s < 192 (2 is a primitive 192nd root of unity, 2^96 = -1); a may be any 64-bit
@@ -125,7 +262,11 @@ GF_HD uint64_t mul_pow2(uint64_t a, unsigned s) {
   } else if (s < 32) {
     // a*2^s = hi*2^64 + lo, hi < 2^32:  lo + hi*(2^32-1)
     const uint64_t lo = a << s, hi = a >> (64 - s);
+#if defined(GF_ASM)
+    r = dev::mad_eps_fold(uint32_t(hi), lo);
+#else
     r = add(lo, (hi << 32) - hi);
+#endif
   } else if (s < 64) {
     // a*2^s = top*2^96 + mid*2^64 + lh*2^32 (the low word of a << s is zero)
     //       = (lh + mid)*2^32 - (mid + top).  The 33-bit sum lh + mid = c*2^32 + xhi folds its carry as
