@@ -1,0 +1,208 @@
+// Device-side canonical form of a residue register: strong carry with wrap-around, equality and res64 without
+// reading the register back.  The reference does this on the host: D2H of the whole register and a
+// sequential O(n) carry loop (include/marin/engine_gpu.h:1534-1561, include/marin/engine.h:148-157,257-295).
+//
+// Input: a normalised digit register (run carries and small subtraction applied; u32 digits in tile-major order,
+// the last digit of a run may exceed its width).  Output: the n digits in NATURAL order, each < 2^width, the value
+// 2^p - 1 mapped to 0 (engine.h:188-196), in a u32 array.
+//   k_gather      tile-major -> natural order
+//   k_local x 3   d'[j] = (d[j] mod 2^w_j) + (d[j-1] >> w_{j-1}), cyclic: carries shrink by a factor 2^w per pass, so
+//                 after them every digit is <= 2^w_j (checked: flag [1]) and what is left is a 0/1 carry chain
+//   k_scan_blocks (generate, propagate) of each block of 4096 digits;  k_scan_top: the carry into every block,
+//                 closed cyclically (2^p = 1: the carry out of the last digit enters digit 0)
+//   k_apply       resolves the chain inside each block
+// Widths are recomputed from ceil(p j / n) (ibdwt.h:127-132), no table.  HBM-bound, ~6 sweeps of 4n bytes: a Gerbicz
+// check moves a few words over PCIe instead of two registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mi355 {
+namespace {
+
+struct CanonGeom { uint32_t p, n, logn2, r5, M1, M2, C; };   // n = r5 * 2^logn2
+
+__device__ __forceinline__ uint64_t ceil_pj_n(const CanonGeom& g, uint64_t j) {
+  const uint64_t x = uint64_t(g.p) * j + (g.n - 1);
+  const uint64_t y = x >> g.logn2;
+  return g.r5 == 5 ? y / 5 : y;
+}
+__device__ __forceinline__ uint32_t width_of(const CanonGeom& g, uint64_t j) { return uint32_t(ceil_pj_n(g, j + 1) - ceil_pj_n(g, j)); }
+
+// memory position of natural digit j (plan.hpp Plan::pos)
+__device__ __forceinline__ size_t pos_of(const CanonGeom& g, uint32_t j) {
+  const uint32_t i = j >> 1, b = j & 1;
+  const uint32_t i1 = i / g.M2, i2 = i - i1 * g.M2;
+  const uint32_t T = i2 / g.C, c = i2 - T * g.C;
+  return ((size_t(T) * g.M1 + i1) * g.C + c) * 2 + b;
+}
+
+__global__ void __launch_bounds__(256) k_gather(CanonGeom g, const uint32_t* __restrict__ digits, uint32_t* __restrict__ nat) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < g.n) nat[j] = digits[pos_of(g, j)];
+}
+
+__global__ void __launch_bounds__(256) k_local(CanonGeom g, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= g.n) return;
+  const uint32_t jp = j ? j - 1 : g.n - 1;
+  const uint64_t o0 = ceil_pj_n(g, jp), o1 = ceil_pj_n(g, uint64_t(jp) + 1), o2 = ceil_pj_n(g, uint64_t(j) + 1);
+  const uint32_t wp = uint32_t(o1 - o0);
+  const uint32_t w = uint32_t(o2 - (j ? o1 : 0));   // for j = 0 the previous digit is n - 1: o1 = p, offset of digit 0 is 0
+  out[j] = (in[j] & ((1u << w) - 1u)) + (in[jp] >> wp);
+}
+
+constexpr int kPerThread = 16, kBlockDigits = 256 * kPerThread;
+
+// (G, P) of the thread's digits / of the block.  Digit value v <= 2^w: generates iff v == 2^w, propagates iff v == 2^w - 1.
+__global__ void __launch_bounds__(256) k_scan_blocks(CanonGeom g, const uint32_t* __restrict__ nat, uint32_t* __restrict__ agg, uint32_t* __restrict__ err) {
+  __shared__ uint32_t sg[256], sp[256];
+  const uint32_t t = threadIdx.x, j0 = blockIdx.x * kBlockDigits + t * kPerThread;
+  uint32_t G = 0, Pm = 1;
+  uint64_t o = (j0 < g.n) ? ceil_pj_n(g, j0) : 0;
+  for (int k = 0; k < kPerThread; ++k) {
+    const uint32_t j = j0 + k;
+    if (j >= g.n) break;
+    const uint64_t on = ceil_pj_n(g, uint64_t(j) + 1);
+    const uint32_t w = uint32_t(on - o); o = on;
+    const uint32_t v = nat[j];
+    if (v > (1u << w)) atomicOr(err, 1u);   // cannot happen after the local passes (the caller falls back to the host carry)
+    const uint32_t gj = v >> w, pj = (v == (1u << w) - 1u) ? 1u : 0u;
+    G = gj | (pj & G);
+    Pm &= pj;
+  }
+  sg[t] = G; sp[t] = Pm;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t bg = 0, bp = 1;
+    for (int i = 0; i < 256; ++i) { bg = sg[i] | (sp[i] & bg); bp &= sp[i]; }
+    agg[blockIdx.x] = bg | (bp << 1);
+  }
+}
+
+// carry into every block (cin[b]); flags[0] = 1 when the value is 2^p - 1 (every digit propagates, nothing generates)
+__global__ void k_scan_top(const uint32_t* __restrict__ agg, uint32_t nblocks, uint32_t* __restrict__ cin, uint32_t* __restrict__ flags) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t G = 0, Pm = 1;
+  for (uint32_t b = 0; b < nblocks; ++b) { const uint32_t a = agg[b]; G = (a & 1u) | ((a >> 1) & G); Pm &= (a >> 1); }
+  uint32_t c = Pm ? 0u : G;   // the carry out of the last digit re-enters digit 0; with P_total it could be anything: take 0
+  flags[0] = (Pm && !G) ? 1u : 0u;
+  for (uint32_t b = 0; b < nblocks; ++b) { cin[b] = c; const uint32_t a = agg[b]; c = (a & 1u) | ((a >> 1) & c); }
+}
+
+__global__ void __launch_bounds__(256) k_apply(CanonGeom g, const uint32_t* __restrict__ nat, const uint32_t* __restrict__ cin, const uint32_t* __restrict__ flags,
+                                               uint32_t* __restrict__ out) {
+  __shared__ uint32_t sg[256], sp[256], sc[256];
+  const uint32_t t = threadIdx.x, j0 = blockIdx.x * kBlockDigits + t * kPerThread;
+  uint32_t v[kPerThread], w[kPerThread];
+  uint32_t G = 0, Pm = 1;
+  uint64_t o = (j0 < g.n) ? ceil_pj_n(g, j0) : 0;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const uint32_t j = j0 + k;
+    v[k] = 0; w[k] = 1;
+    if (j < g.n) {
+      const uint64_t on = ceil_pj_n(g, uint64_t(j) + 1);
+      w[k] = uint32_t(on - o); o = on;
+      v[k] = nat[j];
+      const uint32_t gj = v[k] >> w[k], pj = (v[k] == (1u << w[k]) - 1u) ? 1u : 0u;
+      G = gj | (pj & G);
+      Pm &= pj;
+    }
+  }
+  sg[t] = G; sp[t] = Pm;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t c = cin[blockIdx.x];
+    for (int i = 0; i < 256; ++i) { sc[i] = c; c = sg[i] | (sp[i] & c); }
+  }
+  __syncthreads();
+  uint32_t c = sc[t];
+  const bool zero = flags[0] != 0;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const uint32_t j = j0 + k;
+    if (j < g.n) {
+      const uint32_t s = v[k] + c;
+      out[j] = zero ? 0u : (s & ((1u << w[k]) - 1u));
+      c = s >> w[k];
+    }
+  }
+}
+
+// natural order -> tile-major (set_digits / set_words without the host-side re-tiling)
+__global__ void __launch_bounds__(256) k_scatter(CanonGeom g, const uint32_t* __restrict__ nat, uint32_t* __restrict__ digits) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < g.n) digits[pos_of(g, j)] = nat[j];
+}
+// a small constant spread over the first digits (the register is zero otherwise)
+__global__ void k_set_small(CanonGeom g, uint32_t* __restrict__ digits, uint32_t value) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t v = value;
+  for (uint32_t j = 0; j < g.n && v; ++j) {
+    const uint32_t w = width_of(g, j);
+    digits[pos_of(g, j)] = uint32_t(v & ((uint64_t(1) << w) - 1));
+    v >>= w;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_compare(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t n, uint32_t* __restrict__ diff) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  const bool ne = (j < n) && (a[j] != b[j]);
+  if (__any(ne) && (threadIdx.x & 63) == 0) atomicOr(diff, 1u);
+}
+
+CanonGeom geom_of(const DevPlan& pl, uint32_t p) {
+  CanonGeom g;
+  g.p = p; g.n = pl.n; g.r5 = pl.r5; g.M1 = pl.M1; g.M2 = pl.M2; g.C = pl.C;
+  g.logn2 = 0;
+  while ((uint64_t(pl.r5) << g.logn2) < pl.n) ++g.logn2;
+  return g;
+}
+
+}  // namespace
+
+size_t canon_scratch_words(const DevPlan& pl) {
+  const size_t nb = (size_t(pl.n) + kBlockDigits - 1) / kBlockDigits;
+  return 2 * size_t(pl.n) + 2 * nb + 16;   // two digit arrays, block aggregates, block carries, flags
+}
+
+// digits: normalised register (tile-major).  out: n canonical digits, natural order.  scratch: canon_scratch_words() u32.
+// flags (device, inside scratch; the caller clears them): [0] value was 2^p - 1 (written as 0), [1] a digit was still
+// too wide for the 0/1 carry chain (sticky; the caller then uses the host carry), [2] compare result (sticky).
+hipError_t canon_launch(const DevPlan& pl, uint32_t p, const uint32_t* digits, uint32_t* out, uint32_t* scratch, hipStream_t s) {
+  const CanonGeom g = geom_of(pl, p);
+  const uint32_t n = pl.n, nb = (n + kBlockDigits - 1) / kBlockDigits, ge = (n + 255) / 256;
+  uint32_t* A = scratch;
+  uint32_t* B = scratch + n;
+  uint32_t* agg = scratch + 2 * size_t(n);
+  uint32_t* cin = agg + nb;
+  uint32_t* flags = cin + nb;
+  hipLaunchKernelGGL(k_gather, dim3(ge), dim3(256), 0, s, g, digits, A);
+  hipLaunchKernelGGL(k_local, dim3(ge), dim3(256), 0, s, g, A, B);
+  hipLaunchKernelGGL(k_local, dim3(ge), dim3(256), 0, s, g, B, A);
+  hipLaunchKernelGGL(k_local, dim3(ge), dim3(256), 0, s, g, A, B);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, g, B, agg, flags + 1);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, s, agg, nb, cin, flags);
+  hipLaunchKernelGGL(k_apply, dim3(nb), dim3(256), 0, s, g, B, cin, flags, out);
+  return hipGetLastError();
+}
+uint32_t* canon_flags(const DevPlan& pl, uint32_t* scratch) {
+  const size_t nb = (size_t(pl.n) + kBlockDigits - 1) / kBlockDigits;
+  return scratch + 2 * size_t(pl.n) + 2 * nb;
+}
+hipError_t canon_scatter(const DevPlan& pl, uint32_t p, const uint32_t* nat, uint32_t* digits, hipStream_t s) {
+  hipLaunchKernelGGL(k_scatter, dim3((pl.n + 255) / 256), dim3(256), 0, s, geom_of(pl, p), nat, digits);
+  return hipGetLastError();
+}
+hipError_t canon_set_small(const DevPlan& pl, uint32_t p, uint32_t* digits, uint32_t value, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_small, dim3(1), dim3(64), 0, s, geom_of(pl, p), digits, value);
+  return hipGetLastError();
+}
+hipError_t canon_compare(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* diff_flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_compare, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, diff_flag);
+  return hipGetLastError();
+}
+
+}  // namespace mi355

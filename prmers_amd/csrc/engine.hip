@@ -135,6 +135,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     width_[j] = uint8_t(pl_.width_of_s(s));
     s += pl_.t; if (s >= pl_.n) s -= pl_.n;
   }
+  { const char* hc = std::getenv("MI355_HOST_CARRY"); host_carry_ = hc && hc[0] == '1'; }
   HIPCHK(hipStreamSynchronize(stream_));
   if (verbose_) std::fprintf(stderr, "[mi355] p=%u %s regs=%zu device=%d\n", p, pl_.describe().c_str(), nregs_, device_);
 }
@@ -149,6 +150,7 @@ Engine::~Engine() {
   if (tables_) (void)hipFree(tables_);
   if (di_) (void)hipFree(di_);
   if (f0_) (void)hipFree(f0_);
+  if (canon_) (void)hipFree(canon_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -238,22 +240,57 @@ void Engine::run_back(size_t r, uint32_t a) {
 // ---- host digit I/O -------------------------------------------------------------------------
 
 void Engine::write_values(size_t dst, const std::vector<uint32_t>& natural) {
-  stage_.resize(pl_.n);
-  const size_t M2 = pl_.M2, C = pl_.C, M1 = pl_.M1;
-  for (size_t i = 0; i < pl_.m; ++i) {
-    const size_t i1 = i / M2, i2 = i % M2, T = i2 / C, c = i2 % C;
-    const size_t s = ((T * M1 + i1) * C + c) * 2;
-    stage_[s] = natural[2 * i];
-    stage_[s + 1] = natural[2 * i + 1];
-  }
+  // natural order goes up as it is; the tile-major order is made on the device (canon.hip k_scatter)
   HIPCHK(hipSetDevice(device_));
   HIPCHK(hipStreamSynchronize(stream_));
-  HIPCHK(hipMemcpy(digits(dst), stage_.data(), pl_.n * 4, hipMemcpyHostToDevice));
+  uint32_t* nat = reinterpret_cast<uint32_t*>(work());
+  HIPCHK(hipMemcpy(nat, natural.data(), pl_.n * 4, hipMemcpyHostToDevice));
+  HIPCHK(canon_scatter(dp_, pl_.p, nat, digits(dst), stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
   kind_[dst] = kDigits;
   pending_carry_[dst] = 0; pending_sub_[dst] = 0;
 }
 
+// canonical digits of register r (strong carry with wrap-around, 2^p - 1 -> 0) in natural order, on the device
+uint32_t* Engine::canon_digits(size_t r, int slot) {
+  need_digits(r, "get");
+  HIPCHK(hipSetDevice(device_));
+  const size_t sw = canon_scratch_words(dp_);
+  if (!canon_) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&canon_), (sw + 2 * pl_.n) * 4));
+    HIPCHK(hipMemsetAsync(canon_flags(dp_, canon_), 0, 16 * 4, stream_));
+  }
+  normalize(r);
+  uint32_t* out = canon_ + sw + size_t(slot) * pl_.n;
+  HIPCHK(canon_launch(dp_, pl_.p, digits(r), out, canon_, stream_));
+  return out;
+}
+
+// flags: [0] all ones, [1] chain too wide (fall back), [2] compare differs; clears the sticky ones for the next use
+bool Engine::canon_flags_ok(uint32_t (&flags)[4]) {
+  uint32_t* df = canon_flags(dp_, canon_);
+  HIPCHK(hipMemcpyAsync(flags, df, 16, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipMemsetAsync(df, 0, 16 * 4, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  return flags[1] == 0;
+}
+
 void Engine::read_values(size_t src, std::vector<uint64_t>& v) {
+  if (host_carry_) { read_values_host(src, v); return; }
+  uint32_t* d = canon_digits(src, 0);
+  uint32_t flags[4];
+  stage_.resize(pl_.n);
+  HIPCHK(hipMemcpyAsync(stage_.data(), d, pl_.n * 4, hipMemcpyDeviceToHost, stream_));
+  if (!canon_flags_ok(flags)) { read_values_host(src, v); return; }
+  v.resize(pl_.n);
+  if (flags[0]) {   // 2^p - 1: the reference's get() leaves the digits all ones (engine.h:188-196 maps them to 0 later)
+    for (size_t k = 0; k < pl_.n; ++k) v[k] = (uint64_t(1) << width_[k]) - 1;
+  } else {
+    for (size_t k = 0; k < pl_.n; ++k) v[k] = stage_[k];
+  }
+}
+
+void Engine::read_values_host(size_t src, std::vector<uint64_t>& v) {
   need_digits(src, "get");
   stage_.resize(pl_.n);
   HIPCHK(hipSetDevice(device_));
@@ -289,15 +326,9 @@ void Engine::set_u32(size_t dst, uint32_t value) {
   check_reg(dst);
   HIPCHK(hipSetDevice(device_));
   HIPCHK(hipMemsetAsync(digits(dst), 0, pl_.n * 4, stream_));
-  HIPCHK(hipStreamSynchronize(stream_));
   // spread the constant over the first digits (the reference stores it whole in digit 0,
   // engine_gpu.h:1444-1449; same value, but never an over-wide digit)
-  uint64_t v = value;
-  for (size_t j = 0; j < pl_.n && v; ++j) {
-    const uint32_t d = uint32_t(v & ((uint64_t(1) << width_[j]) - 1));
-    v >>= width_[j];
-    if (d) HIPCHK(hipMemcpy(digits(dst) + pl_.pos(j), &d, 4, hipMemcpyHostToDevice));
-  }
+  if (value) HIPCHK(canon_set_small(dp_, pl_.p, digits(dst), value, stream_));
   kind_[dst] = kDigits;
   pending_carry_[dst] = 0; pending_sub_[dst] = 0;
 }
@@ -319,9 +350,20 @@ void Engine::get_digits(size_t src, uint64_t* d, size_t count) {
 
 uint64_t Engine::res64(size_t src) {
   std::vector<uint64_t> v;
-  read_values(src, v);
+  size_t have = pl_.n;
+  if (host_carry_) {
+    read_values_host(src, v);
+  } else {
+    // the low 64 bits live in the first few digits: canonicalise on the device, read back only those
+    uint32_t* d = canon_digits(src, 0);
+    have = std::min<size_t>(pl_.n, 16);
+    uint32_t head[16], flags[4];
+    HIPCHK(hipMemcpyAsync(head, d, have * 4, hipMemcpyDeviceToHost, stream_));
+    if (!canon_flags_ok(flags)) { read_values_host(src, v); have = pl_.n; }
+    else { v.resize(have); for (size_t k = 0; k < have; ++k) v[k] = flags[0] ? (uint64_t(1) << width_[k]) - 1 : head[k]; }
+  }
   uint64_t r64 = 0; unsigned s = 0;   // engine.h:257-269
-  for (size_t k = 0; k < pl_.n; ++k) {
+  for (size_t k = 0; k < have; ++k) {
     r64 += v[k] << s;
     s += width_[k];
     if (s >= 64) break;
@@ -378,9 +420,24 @@ void Engine::set_words(size_t dst, const uint32_t* w, size_t count) {
 }
 
 bool Engine::equal(size_t lhs, size_t rhs) {
-  std::vector<uint32_t> a(word_count()), b(word_count());
-  get_words(lhs, a.data(), a.size());
-  get_words(rhs, b.data(), b.size());
+  if (!host_carry_) {
+    // both registers canonicalised and compared on the device: 16 bytes cross PCIe (the reference reads both
+    // registers back and carries them on the host: engine.h:148-157 via engine_gpu.h:1534-1561)
+    uint32_t* a = canon_digits(lhs, 0);
+    uint32_t* b = canon_digits(rhs, 1);
+    HIPCHK(canon_compare(a, b, uint32_t(pl_.n), canon_flags(dp_, canon_) + 2, stream_));
+    uint32_t flags[4];
+    if (canon_flags_ok(flags)) return flags[2] == 0;
+  }
+  std::vector<uint64_t> a, b;
+  read_values_host(lhs, a);
+  read_values_host(rhs, b);
+  auto all_ones = [&](const std::vector<uint64_t>& v) {
+    for (size_t k = 0; k < pl_.n; ++k) if (v[k] != (uint64_t(1) << width_[k]) - 1) return false;
+    return true;
+  };
+  if (all_ones(a)) std::fill(a.begin(), a.end(), 0);   // 2^p - 1 == 0
+  if (all_ones(b)) std::fill(b.begin(), b.end(), 0);
   return a == b;
 }
 

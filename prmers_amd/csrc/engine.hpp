@@ -70,6 +70,9 @@ class Engine {
   void materialize(size_t r);        // kFront -> kDigits
   void check_device_error();
   void read_values(size_t src, std::vector<uint64_t>& v);   // natural order, strongly carried digits
+  void read_values_host(size_t src, std::vector<uint64_t>& v);   // the same through D2H + host carry (reference's way)
+  uint32_t* canon_digits(size_t r, int slot);   // device: canonical digits of r in natural order (canon.hip), slot 0 / 1
+  bool canon_flags_ok(uint32_t (&flags)[4]);    // reads the flag words; false: fall back to the host carry
   void write_values(size_t dst, const std::vector<uint32_t>& natural);
   void square_chain(size_t r, uint32_t a, hipEvent_t* ev);
   uint64_t* cbuf(size_t r) { return cbuf_ + r * pl_.runs(); }
@@ -100,6 +103,8 @@ class Engine {
   bool v2rows_ = false, v2cols_ = false;
   std::vector<uint8_t> width_;   // natural order
   std::vector<uint32_t> stage_;  // host staging (one register of digits)
+  uint32_t* canon_ = nullptr;    // device scratch of the canonicalisation: work arrays + two outputs of n digits (lazy)
+  bool host_carry_ = false;      // MI355_HOST_CARRY=1: compare / res64 / read-back through the host (A/B tests)
 };
 
 }  // namespace mi355

@@ -44,4 +44,12 @@ hipError_t v2_launch_back_then_front(const DevPlan& pl, uint64_t* W, uint32_t* s
                                      uint32_t* err, hipStream_t s);
 hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s);
 
+// device-side canonical form (canon.hip): strong carry with wrap-around into natural order, compare, scatter
+size_t canon_scratch_words(const DevPlan& pl);
+hipError_t canon_launch(const DevPlan& pl, uint32_t p, const uint32_t* digits, uint32_t* out, uint32_t* scratch, hipStream_t s);
+uint32_t* canon_flags(const DevPlan& pl, uint32_t* scratch);
+hipError_t canon_compare(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* diff_flag, hipStream_t s);
+hipError_t canon_scatter(const DevPlan& pl, uint32_t p, const uint32_t* nat, uint32_t* digits, hipStream_t s);
+hipError_t canon_set_small(const DevPlan& pl, uint32_t p, uint32_t* digits, uint32_t value, hipStream_t s);
+
 }  // namespace mi355
