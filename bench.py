@@ -9,7 +9,11 @@ no data-path collective: SURVEY.md 8e).  The residue vector is resident in HBM b
 region.  Rank 0 prints ONE JSON line.  Extra objects:
   roofline     -- dominant kernel: algorithmic bytes per launch (16*n: one read+write sweep of the
                   8-byte residue vector, SURVEY.md 8d: 48*n per squaring = 3 sweeps) / its average
-                  duration from HIP events on the engine's stream, against the 8 TB/s HBM peak
+                  duration from HIP events on the engine's stream (one event between kernels, minus the
+                  measured cost of an event record: agrees with rocprofv3 --kernel-trace), against the
+                  8 TB/s HBM peak
+  preheat      -- untimed squarings before --warmup until the GPU clock has ramped (a cold box runs the
+                  first tens of milliseconds slower; --steps/--warmup keep their meaning)
   cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference has no CPU
                   implementation of this path) timed on this box's host cores, N=1 only
 """
@@ -63,6 +67,10 @@ def main():
     ap.add_argument("--exponent", type=int, default=0, help="override the exponent (testing)")
     ap.add_argument("--plan", type=str, default=None, help="plan override, e.g. m2=4096,c=4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat-seconds", type=float, default=2.0,
+                    help="untimed clock ramp before the warm-up: at least this long and until two batches agree within 1 %% (0: off)")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="let the status reduction fall back to gloo when RCCL cannot start (otherwise that is an error)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo to rehearse")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1,
                     help="rehearsal only: put every rank on this device (implies a gloo status reduction)")
@@ -91,7 +99,10 @@ def main():
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
             except Exception as exc:   # pragma: no cover - needs a broken fabric
-                sys.stderr.write("[bench] RCCL unavailable (%s); status reduction falls back to gloo\n" % exc)
+                if not args.allow_gloo:
+                    sys.stderr.write("[bench] RCCL unavailable (%s); pass --allow-gloo to reduce the status word over gloo instead\n" % exc)
+                    raise SystemExit(3)
+                sys.stderr.write("[bench] RCCL unavailable (%s); status reduction falls back to gloo (--allow-gloo)\n" % exc)
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 dist.init_process_group("gloo")
@@ -107,6 +118,18 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # clock ramp (untimed, not part of --warmup): batches of squarings until the rate has settled
+    preheat_iters, preheat_ms = 0, 0.0
+    if args.preheat_seconds > 0:
+        last, t_start = None, time.perf_counter()
+        while True:
+            ms, _ = eng.time_square_mul(0, 500)
+            preheat_iters += 500; preheat_ms += ms
+            spent = time.perf_counter() - t_start
+            settled = last is not None and abs(ms - last) <= 0.01 * last
+            if (spent >= args.preheat_seconds and settled) or spent >= 4 * args.preheat_seconds:
+                break
+            last = ms
     eng.time_square_mul(0, max(1, args.warmup))
     torch.cuda.synchronize()
     barrier()
@@ -131,8 +154,18 @@ def main():
     ll_ms, _ = eng.time_square_mul(0, ll_iters, sub=2)
     # second, instrumented pass of the same loop: per-kernel durations from event pairs on the engine stream
     _, kern = eng.time_square_mul(0, min(args.steps, 64), per_kernel=True)
+    # a Gerbicz-style check at this size: device-side canonical form + compare, and res64
+    check = None
+    if rank == 0:
+        eng.copy(1, 0)
+        eng.is_equal(0, 1); eng.res64(0)   # allocate the scratch, warm the kernels
+        tc0 = time.perf_counter(); same = eng.is_equal(0, 1); tc1 = time.perf_counter(); eng.res64(0); tc2 = time.perf_counter()
+        check = {"is_equal_ms": round(1e3 * (tc1 - tc0), 3), "res64_ms": round(1e3 * (tc2 - tc1), 3), "equal": bool(same),
+                 "pcie_bytes_per_check": 16, "note": "strong carry, compare and res64 on the device (canon.hip)"}
     if rank == 0:
         n = eng.n
+        event_overhead = kern.pop("event_overhead", 0.0)
+        kern = {k: v for k, v in kern.items() if v >= 0}   # slots this path does not launch are reported as -1
         chain = {k: v for k, v in kern.items() if k != "k_sub_small"}
         dom = max(chain, key=chain.get)
         dom_ms = chain[dom]
@@ -167,12 +200,16 @@ def main():
                                       (" [REHEARSAL: all ranks on one device]" if rehearsal else "")},
             "event_ms_per_step": round(ev_ms / args.steps, 5),
             "ll_ms_per_step": round(ll_ms / ll_iters, 5),
+            "preheat_iters": preheat_iters, "preheat_ms": round(preheat_ms, 1),
+            "gerbicz_check": check,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
                          "binding_roof": "VALU issue (integer GF(P) arithmetic), see DESIGN.md section 5",
                          "algorithmic_bytes_per_launch": sweep_bytes,
                          "kernel_ms": {k: round(v, 5) for k, v in kern.items()},
+                         "kernel_ms_sum": round(sum(chain.values()), 5), "event_record_ms_subtracted": round(event_overhead, 5),
+                         "traffic_source": "profiles/traffic_latest.json (rocprofv3 --pmc passes of this command, tools/profile.sh)" if traffic else None,
                          "iteration": {"algorithmic_bytes": 48 * n,
                                        "achieved": round(48 * n / (ms_per_step * 1e-3) / 1e9, 1),
                                        "frac": round(48 * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},

@@ -118,7 +118,12 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     // at 126 VGPRs and the sweeps are VALU-bound, so saving the digit round trip and one kernel boundary does
     // not pay; kept selectable with MI355_FUSED=1, off by default)
     const char* fz = std::getenv("MI355_FUSED");
+#if defined(MI355_EXPERIMENTAL)
     fused_ = v2cols_ && fz && (fz[0] == '1' || fz[0] == '2');
+#else
+    if (fz && (fz[0] == '1' || fz[0] == '2'))
+      throw std::runtime_error("MI355_FUSED needs the experimental library (make -C prmers_amd/csrc exp; MI355_ENGINE_LIB=.../libmi355_engine_exp.so)");
+#endif
     chained_ = fused_ && fz[0] == '2';   // back and front sweeps as two halves of one launch instead of one fused kernel
     if (fused_) {
       const size_t tiles = pl_.tiles();
@@ -594,10 +599,14 @@ void Engine::set_checkpoint(const void* data, size_t size) {
 // ---- measurement ----------------------------------------------------------------------------
 
 const char* Engine::kernel_name(size_t k) {
-  static const char* names[kKernels] = {"k_front", "k_middle", "k_back", "k_carry_fix", "k_sub_small"};
+  static const char* names[kKernels] = {"k_front", "k_middle", "k_back", "k_carry_fix", "k_sub_small", "event_overhead"};
   return k < kKernels ? names[k] : "";
 }
 
+// kernel_ms[k]: average duration of kernel k of one squaring (-1: that kernel is not launched on this path),
+// from one event between consecutive kernels on the engine's stream, minus the cost of an event record itself
+// (kernel_ms[5], measured as the spacing of back-to-back records on the same stream: without the subtraction every
+// interval carries one record, ~4-5 us, and a path that launches no kernel between two records shows it as a kernel).
 void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, double* total_ms, double* kernel_ms, size_t kcount) {
   need_digits(r, "time_square_mul");
   if (a == 0 || iters == 0) throw std::runtime_error("time_square_mul: factor and iters must be >= 1");
@@ -623,6 +632,15 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
     const size_t per = 6;
     std::vector<hipEvent_t> ev(reps * per);
     for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+    // cost of one event record: spacing of back-to-back records
+    double overhead = 0;
+    {
+      for (size_t i = 0; i < reps * per; ++i) HIPCHK(hipEventRecord(ev[i], stream_));
+      HIPCHK(hipStreamSynchronize(stream_));
+      float t = 0;
+      HIPCHK(hipEventElapsedTime(&t, ev[per], ev[reps * per - 1]));   // skip the first records (queue start-up)
+      overhead = double(t) / double(reps * per - 1 - per);
+    }
     for (size_t i = 0; i < reps; ++i) {
       square_chain(r, a, &ev[i * per]);
       if (sub) sub_u32(r, sub);
@@ -636,6 +654,12 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
         kernel_ms[k] += double(t) / double(reps);
       }
     for (auto& x : ev) HIPCHK(hipEventDestroy(x));
+    // which of the five slots hold a kernel on this path
+    const bool fix_now = !fused_ && !v2cols_ && pl_.C < 2;                        // k_carry_fix right after the back sweep
+    const bool sub_kernel = sub != 0 && !(v2cols_ && sub < (1u << 30));          // k_sub_small (else folded into the next front sweep)
+    const bool launched[5] = {true, true, true, fix_now, sub_kernel};
+    for (size_t k = 0; k < 5 && k < kcount; ++k) kernel_ms[k] = launched[k] ? std::max(0.0, kernel_ms[k] - overhead) : -1.0;
+    if (kcount > 5) kernel_ms[5] = overhead;
   }
 }
 

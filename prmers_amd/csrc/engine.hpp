@@ -51,7 +51,7 @@ class Engine {
   void set_checkpoint(const void* data, size_t size);
 
   // measurement
-  static constexpr size_t kKernels = 5;
+  static constexpr size_t kKernels = 6;   // five kernel slots of a squaring + the measured cost of an event record
   static const char* kernel_name(size_t k);
   void time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, double* total_ms, double* kernel_ms, size_t kcount);
   size_t algorithmic_bytes() const { return 48 * pl_.n; }

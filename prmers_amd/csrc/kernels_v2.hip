@@ -616,6 +616,7 @@ __global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __
   }
 }
 
+#if defined(MI355_EXPERIMENTAL)   // not in the shipped library: make -C prmers_amd/csrc exp
 // ---------------------------------------------------------------------------------------------
 // Fused back + front sweep (work buffer -> work buffer, in place): the residue never goes to memory as
 // digits between two squarings and one of the three kernel boundaries per squaring disappears.  One tile
@@ -762,6 +763,9 @@ __global__ void __launch_bounds__(512, 4) k3k1_cols(DevPlan pl, uint64_t* __rest
 }
 
 }  // namespace v2
+#else
+}  // namespace v2
+#endif
 
 namespace v2 {
 // chain starts and ratios of the four-step twiddle chains of the column kernels (same thread map as the last
@@ -812,8 +816,10 @@ hipError_t v2_configure() {
   MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes)
   MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
+#if defined(MI355_EXPERIMENTAL)
   MI355_SET_LDS(v2::k3k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k31_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<4>, v2::kLdsBytes)
+#endif
   return hipSuccess;
 }
 #undef MI355_SET_LDS
@@ -845,6 +851,7 @@ hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits
   }
   return hipGetLastError();
 }
+#if defined(MI355_EXPERIMENTAL)
 hipError_t v2_launch_back_then_front(const DevPlan& pl, uint64_t* W, uint32_t* scratch, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a,
                                      uint32_t* err, hipStream_t s) {
   const dim3 grid(2 * (pl.M2 / pl.C)), block(512);
@@ -864,5 +871,10 @@ hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, ui
   }
   return hipGetLastError();
 }
+
+#else
+hipError_t v2_launch_back_then_front(const DevPlan&, uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t, uint32_t, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t v2_launch_back_front(const DevPlan&, uint64_t*, uint64_t*, uint32_t*, uint32_t, uint32_t, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+#endif
 
 }  // namespace mi355

@@ -167,7 +167,7 @@ def shard_worktodo(lines, rank, world):
 # the driver
 # ---------------------------------------------------------------------------------------------
 def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, max_iters=None,
-                  log=None, ckpt_path=None, backup_every=0, resume=None, stop_after_s=None):
+                  log=None, ckpt_path=None, backup_every=0, resume=None, stop_after_s=None, on_check=None):
     """One PRP (mode "prp") or LL-unsafe (mode "ll") test of 2^p-1 on `eng` (>= 8 registers).
 
     Returns a dict: is_prime, res64, res2048, iterations, gerbicz_checks, gerbicz_errors, complete.
@@ -176,6 +176,8 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     resume = {"it": i, "j": j}: continue a PRP right after the passed Gerbicz-Li check of iteration i (the
     caller has put the residue into R0 and the Gerbicz accumulator into R1); stop_after_s: stop at the first
     passed check after that many seconds and return that state in result["state"] (long runs in slices).
+    on_check(passed, iteration) is called after every Gerbicz-Li check (the multi-GPU launcher reduces its status
+    word there).
     """
     import time as _time
     t_start = _time.time()
@@ -241,7 +243,12 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
                     eng.square_mul(R3, 3)
                 for _ in range(modB):
                     eng.square_mul(R3)
-                if eng.get_int(R3) != eng.get_int(R1):
+                # the reference compares two mpz read-backs (RunPrpOrLlMarin.cpp:363-366); here the engine compares the
+                # canonical forms on the device (canon.hip), 16 bytes over PCIe
+                same = eng.is_equal(R3, R1) if hasattr(eng, "is_equal") else eng.get_int(R3) == eng.get_int(R1)
+                if on_check:
+                    on_check(bool(same), it + 1)
+                if not same:
                     log("[Gerbicz Li] Mismatch")
                     log("[Gerbicz Li] Check FAILED! iter=%d" % (it + 1))
                     log("[Gerbicz Li] Restore iter=%d (j=%d)" % (itersave, jsave))

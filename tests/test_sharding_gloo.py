@@ -1,6 +1,9 @@
-"""world_size-2 run of the one-exponent-per-rank launcher on CPU (gloo), engines backed by the oracle."""
+"""world_size-2 runs of the one-exponent-per-rank launcher on CPU (gloo), engines backed by the oracle:
+sharding, the status word, reductions at the Gerbicz-check boundaries, and a failing rank."""
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import pytest
@@ -10,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKTODO = ["PRP=1,2,127,-1", "PRP=1,2,521,-1", "Test=607", "PRP=1,2,1001,-1"]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, scenario):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -19,27 +22,77 @@ def _worker(rank, world, port, q):
     from prmers_amd import launch, prp
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res, status = launch.run_sharded(WORKTODO, lambda p: orc.OracleEngine(p, prp.REGISTERS), checklevel=1)
-        q.put((rank, [(r["exponent"], r["mode"], r["is_prime"], r["rank"]) for r in res], status))
+        seen = []
+        if scenario == "plain":
+            res, status = launch.run_sharded(WORKTODO, lambda p: orc.OracleEngine(p, prp.REGISTERS), checklevel=1)
+        elif scenario == "lockstep":   # 521 and 523 have the same number of check boundaries: reduced at every one of them
+            res, status = launch.run_sharded(["PRP=1,2,521,-1", "PRP=1,2,523,-1"], lambda p: orc.OracleEngine(p, prp.REGISTERS), checklevel=1,
+                                             on_status=seen.append)
+        elif scenario == "engine_fails":   # rank 1's engine cannot be created
+            def make(p):
+                if p == 521:
+                    raise RuntimeError("no HIP device available")
+                return orc.OracleEngine(p, prp.REGISTERS)
+            res, status = launch.run_sharded(WORKTODO, make, checklevel=1)
+        elif scenario == "check_fails":   # an injected error on one entry: caught by Gerbicz-Li, rolled back, and reported
+            res, status = launch.run_sharded(["PRP=1,2,9941,-1", "PRP=1,2,127,-1"], lambda p: orc.OracleEngine(p, prp.REGISTERS),
+                                             checklevel=1, erroriter=(9900 if rank == 0 else 0))
+        q.put((rank, [(r["exponent"], r["mode"], r["is_prime"], r["rank"], r.get("error")) for r in res], status, len(seen)))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_a_worktodo():
+def _run(scenario, timeout=300):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=240) for _ in procs]
+    out = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    expected = sorted([(127, "prp", True, 0), (607, "ll", True, 0), (521, "prp", True, 1), (1001, "prp", False, 1)])
-    for rank, res, status in out:
+    return out
+
+
+def test_two_ranks_share_a_worktodo():
+    expected = sorted([(127, "prp", True, 0, None), (607, "ll", True, 0, None), (521, "prp", True, 1, None), (1001, "prp", False, 1, None)])
+    for rank, res, status, _ in _run("plain"):
         assert sorted(res) == expected                      # every rank sees every result
         assert status["all_ok"] == 1 and status["gerbicz_errors"] == 0
         assert status["iterations"] == 127 + 521 + 605 + 1001
+        assert status["check_boundary_reductions"] is False   # the shares have different numbers of checks: exit only
+
+
+def test_status_is_reduced_at_every_check_boundary_when_the_cadence_matches():
+    for rank, res, status, nseen in _run("lockstep"):
+        assert status["all_ok"] == 1 and status["check_boundary_reductions"] is True
+        assert status["iterations"] == 521 + 523
+        assert nseen == 24 + 1                               # 24 Gerbicz-Li checks each (B = 22) + the reduction at exit
+
+
+def test_a_failing_rank_clears_all_ok_and_nobody_hangs():
+    for rank, res, status, _ in _run("engine_fails"):
+        assert status["all_ok"] == 0
+        errs = [r for r in res if r[4]]
+        assert len(errs) == 1 and errs[0][0] == 521 and "no HIP device" in errs[0][4]
+        assert sorted(r[0] for r in res) == [127, 521, 607, 1001]   # the other entries still ran and were gathered
+
+
+def test_a_failed_gerbicz_check_is_counted_and_clears_all_ok():
+    for rank, res, status, _ in _run("check_fails"):
+        assert status["gerbicz_errors"] == 1 and status["all_ok"] == 0
+        assert (9941, "prp", True, 0, None) in res              # the run recovered from the last good state
+
+
+def test_launcher_command_line_dry_run(tmp_path):
+    wt = tmp_path / "worktodo.txt"
+    wt.write_text("\n".join(WORKTODO) + "\n# comment\nPfactor=1,2,999,-1,70,2\n")
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "prmers_amd.launch", "--worktodo", str(wt), "--dry-run"], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr
+    shards = [json.loads(l) for l in out.stdout.splitlines()]
+    assert [e["exponent"] for e in shards[0]["entries"]] == [127, 607] and [e["exponent"] for e in shards[1]["entries"]] == [521, 1001]
