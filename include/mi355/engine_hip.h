@@ -51,6 +51,11 @@ class engine_hip final : public engine {
     size_t (*checkpoint_size)(void*) = nullptr;
     int (*get_checkpoint)(void*, void*, size_t) = nullptr;
     int (*set_checkpoint)(void*, const void*, size_t) = nullptr;
+    int (*addsub)(void*, size_t, size_t, size_t, size_t) = nullptr;
+    int (*addsub_copy)(void*, size_t, size_t, size_t, size_t, size_t, size_t) = nullptr;
+    int (*mul_add)(void*, size_t, size_t, size_t, uint32_t) = nullptr;
+    int (*square_mul_copy)(void*, size_t, size_t, uint32_t) = nullptr;
+    int (*mul_copy)(void*, size_t, size_t, size_t, uint32_t) = nullptr;
 
     template <class F> void bind(F& f, const char* name) {
       f = reinterpret_cast<F>(dlsym(so, name));
@@ -80,6 +85,8 @@ class engine_hip final : public engine {
       bind(register_data_size, "mi355_engine_register_data_size"); bind(get_data, "mi355_engine_get_data");
       bind(set_data, "mi355_engine_set_data"); bind(checkpoint_size, "mi355_engine_checkpoint_size");
       bind(get_checkpoint, "mi355_engine_get_checkpoint"); bind(set_checkpoint, "mi355_engine_set_checkpoint");
+      bind(addsub, "mi355_engine_addsub"); bind(addsub_copy, "mi355_engine_addsub_copy"); bind(mul_add, "mi355_engine_mul_add");
+      bind(square_mul_copy, "mi355_engine_square_mul_copy"); bind(mul_copy, "mi355_engine_mul_copy");
     }
     ~Api() { if (so) dlclose(so); }
   };
@@ -117,6 +124,14 @@ class engine_hip final : public engine {
   void sub(const Reg src, const uint32_t a) const override { ok(_api.sub_u32(_h, src, a), "sub"); }
   void add(const Reg dst, const Reg src) const override { ok(_api.add(_h, dst, src), "add"); }
   void sub_reg(const Reg dst, const Reg src) const override { ok(_api.sub_reg(_h, dst, src), "sub_reg"); }
+  // fused variants: one sweep each in the library instead of the base-class compositions (engine.h:65-131)
+  void mul_add(const Reg dst, const Reg mul_src, const Reg add_src, const uint32_t a = 1) const override { ok(_api.mul_add(_h, dst, mul_src, add_src, a), "mul_add"); }
+  void addsub(const Reg sum_out, const Reg diff_out, const Reg a, const Reg b) const override { ok(_api.addsub(_h, sum_out, diff_out, a, b), "addsub"); }
+  void square_mul_copy(const Reg src, const Reg dst_copy, const uint32_t a = 1) const override { ok(_api.square_mul_copy(_h, src, dst_copy, a), "square_mul_copy"); }
+  void mul_copy(const Reg dst, const Reg src, const Reg dst_copy, const uint32_t a = 1) const override { ok(_api.mul_copy(_h, dst, src, dst_copy, a), "mul_copy"); }
+  void addsub_copy(const Reg sum, const Reg diff, const Reg sum_copy, const Reg diff_copy, const Reg a, const Reg b) const override {
+    ok(_api.addsub_copy(_h, sum, diff, sum_copy, diff_copy, a, b), "addsub_copy");
+  }
   bool is_equal(const Reg lhs, const Reg rhs) const
 #if defined(MI355_HAVE_GMP) || defined(MI355_USE_REFERENCE_ENGINE_H)
       override

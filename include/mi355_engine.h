@@ -59,6 +59,19 @@ MI355_ENGINE_API int mi355_engine_sub_reg(mi355_engine_handle handle, size_t dst
 MI355_ENGINE_API int mi355_engine_sub_u32(mi355_engine_handle handle, size_t dst, uint32_t value);   /* engine::sub, engine.h:62 */
 MI355_ENGINE_API int mi355_engine_equal(mi355_engine_handle handle, size_t lhs, size_t rhs, int* equal_out); /* is_equal, engine.h:148 */
 
+/* ---- fused variants (overridable defaults of the reference's engine, engine.h:65-131; its GPU engine fuses them
+        into the carry kernels, kernels/marin.cl:1856-2365, engine_gpu.h:1960-2110).  One sweep each here too. ---- */
+/* sum_out = a + b, diff_out = a - b (engine.h:72) */
+MI355_ENGINE_API int mi355_engine_addsub(mi355_engine_handle handle, size_t sum_out, size_t diff_out, size_t a, size_t b);
+/* the same, each result also written to a second register (engine.h:125) */
+MI355_ENGINE_API int mi355_engine_addsub_copy(mi355_engine_handle handle, size_t sum, size_t diff, size_t sum_copy, size_t diff_copy, size_t a, size_t b);
+/* dst = dst * mul_src * factor + add_src; mul_src is a multiplicand (engine.h:65) */
+MI355_ENGINE_API int mi355_engine_mul_add(mi355_engine_handle handle, size_t dst, size_t mul_src, size_t add_src, uint32_t factor);
+/* src = src^2 * factor, dst_copy = src (engine.h:81) */
+MI355_ENGINE_API int mi355_engine_square_mul_copy(mi355_engine_handle handle, size_t src, size_t dst_copy, uint32_t factor);
+/* dst = dst * src * factor, dst_copy = dst (engine.h:91) */
+MI355_ENGINE_API int mi355_engine_mul_copy(mi355_engine_handle handle, size_t dst, size_t src, size_t dst_copy, uint32_t factor);
+
 /* ---- rest of the engine surface the Marin callers use ---- */
 /* engine::get / engine::set(Reg, uint64*) (engine.h:24-25): n digits, value | width << 32, strongly
    carried (engine_gpu.h:1534-1561).  count must equal transform_size(). */

@@ -39,8 +39,11 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   HIPCHK(hipMemsetAsync(regs_, 0, (nregs_ + 1) * reg_bytes_, stream_));
   slot_.resize(nregs_ + 1);
   for (size_t r = 0; r <= nregs_; ++r) slot_[r] = regs_ + r * reg_bytes_;
-  HIPCHK(hipMalloc(reinterpret_cast<void**>(&cbuf_), nregs_ * pl_.runs() * 8));
-  HIPCHK(hipMemsetAsync(cbuf_, 0, nregs_ * pl_.runs() * 8, stream_));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&cbuf_), (nregs_ + 4) * pl_.runs() * 8));
+  HIPCHK(hipMemsetAsync(cbuf_, 0, (nregs_ + 4) * pl_.runs() * 8, stream_));
+  cb_.resize(nregs_);
+  for (size_t r = 0; r < nregs_; ++r) cb_[r] = cbuf_ + r * pl_.runs();
+  for (size_t r = nregs_; r < nregs_ + 4; ++r) cb_spare_.push_back(cbuf_ + r * pl_.runs());
   kind_.assign(nregs_, kDigits);
   pending_carry_.assign(nregs_, 0);
   pending_sub_.assign(nregs_, 0);
@@ -452,11 +455,14 @@ void Engine::copy(size_t dst, size_t src) {
   check_reg(dst); check_reg(src);
   if (dst == src) return;
   HIPCHK(hipSetDevice(device_));
-  if (kind_[src] == kDigits) normalize(src);      // a front image is copied as it is (with its deferred subtraction)
-  pending_carry_[dst] = 0;
-  pending_sub_[dst] = (kind_[src] == kFront) ? pending_sub_[src] : 0;
+  // the register is copied as it stands: digits with their pending run carries and small subtraction (no carry sweep),
+  // a front image with its deferred subtraction, a multiplicand image whole
   const size_t bytes = (kind_[src] == kDigits) ? pl_.n * 4 : reg_bytes_;
   HIPCHK(hipMemcpyAsync(slot_[dst], slot_[src], bytes, hipMemcpyDeviceToDevice, stream_));
+  if (kind_[src] == kDigits && pending_carry_[src])
+    HIPCHK(hipMemcpyAsync(cbuf(dst), cbuf(src), pl_.runs() * 8, hipMemcpyDeviceToDevice, stream_));
+  pending_carry_[dst] = (kind_[src] == kDigits) ? pending_carry_[src] : 0;
+  pending_sub_[dst] = (kind_[src] != kImage) ? pending_sub_[src] : 0;
   kind_[dst] = kind_[src];
 }
 
@@ -533,20 +539,122 @@ void Engine::mul(size_t dst, size_t src, uint32_t a) {
   run_back(dst, a);
 }
 
+uint64_t* Engine::take_spare_cbuf() {
+  if (cb_spare_.empty()) throw std::runtime_error("internal: no spare carry buffer");
+  uint64_t* b = cb_spare_.back();
+  cb_spare_.pop_back();
+  return b;
+}
+void Engine::adopt_cbuf(size_t r, uint64_t* fresh) {
+  cb_spare_.push_back(cb_[r]);
+  cb_[r] = fresh;
+}
+
+void Engine::digits_ready(size_t r) {
+  need_digits(r, "add/sub");
+  materialize(r);
+  if (pending_sub_[r]) normalize(r);   // rare: a small subtraction not yet folded into a sweep
+}
+
+// sum -> s1 (and s2), difference -> d1 (and d2); -1: not wanted.  One run-wise sweep on pending-carry digits
+// (kernels.hip k_linear); the results leave their run carries pending for the next front sweep.
+void Engine::linear(long s1, long s2, long d1, long d2, size_t a, size_t b) {
+  HIPCHK(hipSetDevice(device_));
+  digits_ready(a); digits_ready(b);
+  const long outs[4] = {s1, s2, d1, d2};
+  for (int i = 0; i < 4; ++i)
+    if (outs[i] >= 0) { check_reg(size_t(outs[i])); for (int j = 0; j < i; ++j) if (outs[j] == outs[i]) throw std::runtime_error("addsub: output registers must differ"); }
+  LinArgs la;
+  la.a = digits(a); la.ca = pending_carry_[a] ? cbuf(a) : nullptr;
+  la.b = digits(b); la.cb = pending_carry_[b] ? cbuf(b) : nullptr;
+  uint64_t* fresh[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < 4; ++i) if (outs[i] >= 0) fresh[i] = take_spare_cbuf();
+  if (s1 >= 0) { la.s1 = digits(size_t(s1)); la.cs1 = fresh[0]; }
+  if (s2 >= 0) { la.s2 = digits(size_t(s2)); la.cs2 = fresh[1]; }
+  if (d1 >= 0) { la.d1 = digits(size_t(d1)); la.cd1 = fresh[2]; }
+  if (d2 >= 0) { la.d2 = digits(size_t(d2)); la.cd2 = fresh[3]; }
+  if ((s2 >= 0 && s1 < 0) || (d2 >= 0 && d1 < 0)) throw std::runtime_error("internal: copy output without a primary output");
+  HIPCHK(launch_linear(dp_, la, stream_));
+  for (int i = 0; i < 4; ++i)
+    if (outs[i] >= 0) {
+      const size_t r = size_t(outs[i]);
+      adopt_cbuf(r, fresh[i]);
+      kind_[r] = kDigits; pending_carry_[r] = 1; pending_sub_[r] = 0;
+      if (pl_.C < 2) { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }   // runs of two digits: no deferred fold
+    }
+}
+
 void Engine::add(size_t dst, size_t src) {
   need_digits(dst, "add"); need_digits(src, "add");
-  HIPCHK(hipSetDevice(device_));
-  normalize(dst); normalize(src);
-  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf(dst), 0, stream_));
-  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf(dst), stream_));
+  linear(long(dst), -1, -1, -1, dst, src);
 }
 
 void Engine::sub_reg(size_t dst, size_t src) {
   need_digits(dst, "sub_reg"); need_digits(src, "sub_reg");
+  linear(-1, -1, long(dst), -1, dst, src);
+}
+
+void Engine::addsub(size_t sum_out, size_t diff_out, size_t a, size_t b) {
+  need_digits(a, "addsub"); need_digits(b, "addsub");
+  linear(long(sum_out), -1, long(diff_out), -1, a, b);
+}
+
+void Engine::addsub_copy(size_t sum, size_t diff, size_t sum_copy, size_t diff_copy, size_t a, size_t b) {
+  need_digits(a, "addsub_copy"); need_digits(b, "addsub_copy");
+  linear(long(sum), long(sum_copy), long(diff), long(diff_copy), a, b);
+}
+
+// back sweep of work() into dst with the extras of kernels.hpp BackExt
+void Engine::back_ext(size_t dst, uint32_t a, long copy_to, long add_src) {
+  BackExt x;
+  if (copy_to >= 0 && size_t(copy_to) != dst) { check_reg(size_t(copy_to)); x.digits2 = digits(size_t(copy_to)); x.cbuf2 = cbuf(size_t(copy_to)); }
+  if (add_src >= 0) { x.add_digits = digits(size_t(add_src)); x.add_cbuf = pending_carry_[size_t(add_src)] ? cbuf(size_t(add_src)) : nullptr; }
+  uint64_t* fresh = take_spare_cbuf();   // the addend may be dst itself: its pending carries are read while the new ones are written
+  if (v2cols_) HIPCHK(v2_launch_back_ext(dp_, work(), digits(dst), fresh, a, x, stream_));
+  else HIPCHK(launch_back_ext(dp_, work(), digits(dst), fresh, a, x, stream_));
+  adopt_cbuf(dst, fresh);
+  const size_t outs[2] = {dst, x.digits2 ? size_t(copy_to) : dst};
+  for (int i = 0; i < (x.digits2 ? 2 : 1); ++i) {
+    const size_t r = outs[i];
+    kind_[r] = kDigits; pending_sub_[r] = 0; pending_carry_[r] = 1;
+    if (!v2cols_ && pl_.C < 2) { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }
+  }
+}
+
+void Engine::square_mul_copy(size_t src, size_t dst_copy, uint32_t a) {
+  need_digits(src, "square_mul_copy"); check_reg(dst_copy);
+  if (a == 0) throw std::runtime_error("square_mul_copy: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  normalize(dst); normalize(src);
-  HIPCHK(launch_addsub(dp_, digits(dst), digits(src), cbuf(dst), 1, stream_));
-  HIPCHK(launch_carry_fix(dp_, digits(dst), cbuf(dst), stream_));
+  if (fused_ || dst_copy == src) { square_mul(src, a); copy(dst_copy, src); return; }
+  run_front(src);
+  run_middle(work(), nullptr, work(), 0, 0);
+  back_ext(src, a, long(dst_copy), -1);
+}
+
+void Engine::mul_copy(size_t dst, size_t src, size_t dst_copy, uint32_t a) {
+  need_digits(dst, "mul_copy"); check_reg(src); check_reg(dst_copy);
+  if (kind_[src] != kImage) throw std::runtime_error("mul_copy: src must be a multiplicand (set_multiplicand)");
+  if (dst == src || dst_copy == src) throw std::runtime_error("mul_copy: the multiplicand must differ from the outputs");
+  if (a == 0) throw std::runtime_error("mul_copy: factor must be >= 1");
+  HIPCHK(hipSetDevice(device_));
+  if (fused_ || dst_copy == dst) { mul(dst, src, a); copy(dst_copy, dst); return; }
+  run_front(dst);
+  run_middle(work(), image(src), work(), 1, 0);
+  back_ext(dst, a, long(dst_copy), -1);
+}
+
+void Engine::mul_add(size_t dst, size_t mul_src, size_t add_src, uint32_t a) {
+  need_digits(dst, "mul_add"); check_reg(mul_src); need_digits(add_src, "mul_add");
+  if (kind_[mul_src] != kImage) throw std::runtime_error("mul_add: mul_src must be a multiplicand (set_multiplicand)");
+  if (dst == mul_src) throw std::runtime_error("mul_add: dst and mul_src must differ");
+  if (a == 0) throw std::runtime_error("mul_add: factor must be >= 1");
+  HIPCHK(hipSetDevice(device_));
+  if (fused_) { mul(dst, mul_src, a); add(dst, add_src); return; }
+  if (add_src != dst) digits_ready(add_src);
+  else if (kind_[dst] != kDigits || pending_sub_[dst]) normalize(dst);
+  run_front(dst);   // reads digits(dst) (+ pending carries) and leaves them in place
+  run_middle(work(), image(mul_src), work(), 1, 0);
+  back_ext(dst, a, -1, long(add_src));
 }
 
 void Engine::sub_u32(size_t r, uint32_t v) {

@@ -42,6 +42,12 @@ class Engine {
   void sub_reg(size_t dst, size_t src);
   void sub_u32(size_t r, uint32_t v);
   bool equal(size_t lhs, size_t rhs);
+  // fused variants of the reference's engine (include/marin/engine.h:65-131; kernels/marin.cl:1856-2365): one sweep each
+  void addsub(size_t sum_out, size_t diff_out, size_t a, size_t b);
+  void addsub_copy(size_t sum, size_t diff, size_t sum_copy, size_t diff_copy, size_t a, size_t b);
+  void mul_add(size_t dst, size_t mul_src, size_t add_src, uint32_t a);
+  void square_mul_copy(size_t src, size_t dst_copy, uint32_t a);
+  void mul_copy(size_t dst, size_t src, size_t dst_copy, uint32_t a);
 
   size_t register_data_size() const { return reg_bytes_ + 8; }
   void get_data(size_t src, void* data, size_t size);
@@ -75,7 +81,12 @@ class Engine {
   bool canon_flags_ok(uint32_t (&flags)[4]);    // reads the flag words; false: fall back to the host carry
   void write_values(size_t dst, const std::vector<uint32_t>& natural);
   void square_chain(size_t r, uint32_t a, hipEvent_t* ev);
-  uint64_t* cbuf(size_t r) { return cbuf_ + r * pl_.runs(); }
+  uint64_t* cbuf(size_t r) { return cb_[r]; }
+  uint64_t* take_spare_cbuf();                      // carry-word buffers are handed around like the register slots
+  void adopt_cbuf(size_t r, uint64_t* fresh);       // r's pending carries are now in `fresh`; its old buffer becomes spare
+  void digits_ready(size_t r);                      // r as a digit register for a run-wise kernel (front image materialised, small subtraction applied)
+  void linear(long s1, long s2, long d1, long d2, size_t a, size_t b);
+  void back_ext(size_t dst, uint32_t a, long copy_to, long add_src);
   void normalize(size_t r);          // apply deferred run carries / small subtraction
   void run_front(size_t r);          // digits(r) -> work_, consuming pending state when the kernel can
   void run_middle(const uint64_t* in, const uint64_t* y, uint64_t* out, int mode, uint32_t sub);
@@ -93,7 +104,8 @@ class Engine {
   uint32_t* flags_ = nullptr;                 // fused sweep: per-work-group epoch flags (+ error word at the end)
   uint32_t epoch_ = 0;
   bool fused_ = false, chained_ = false;
-  uint64_t* cbuf_ = nullptr;
+  uint64_t* cbuf_ = nullptr;                  // reg_count + 4 buffers of runs() carry words
+  std::vector<uint64_t*> cb_, cb_spare_;      // cb_[r]: the buffer register r uses now
   void* tables_ = nullptr;
   uint64_t* f0_ = nullptr;   // four-step chain starts / ratios of the register-resident column kernels
   uint32_t* di_ = nullptr;   // digit-info words of the register-resident column kernels (plan.hpp DI)

@@ -275,8 +275,22 @@ __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __r
 // ---------------------------------------------------------------------------------------------
 // back: inverse of front + unweight + carry over the tile's M1 runs of 2C digits
 // ---------------------------------------------------------------------------------------------
+// weak carry of a run's incoming carry word into its first digits (adc4, marin.cl:203-212); dd: the run's first four digits
+__device__ __forceinline__ void run_carry_in(const DevPlan& pl, uint32_t sa, uint32_t T, uint64_t cin, uint32_t (&dd)[4]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint32_t width; bool wr;
+    digit_info(pl, sa, pl.SB[2 * (T * pl.C) + k], width, wr);
+    const uint64_t v = uint64_t(dd[k]) + cin;
+    dd[k] = uint32_t(v & ((uint64_t(1) << width) - 1));
+    cin = v >> width;
+  }
+  dd[3] += uint32_t(cin);
+}
+
+template <bool EXT>
 __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
-                                              uint64_t* __restrict__ cbuf, uint32_t a) {
+                                              uint64_t* __restrict__ cbuf, uint32_t a, BackExt ext) {
   P2* X = reinterpret_cast<P2*>(smem_raw);
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;
   // blocks that share an XCD (b, b + 8, ...) take neighbouring tiles: the 64-byte pieces of a work-buffer line meet in one L2
@@ -306,11 +320,26 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
     const uint64_t tai[2] = {pl.TAi[i1], pl.TAi[M1 + i1]};
     const uint64_t tai2[2] = {gf::dbl(tai[0]), gf::dbl(tai[1])};  // wrapped exponents: the weight was halved
     uint64_t carry = 0;
+    uint32_t addh[4] = {0, 0, 0, 0};   // first digits of the addend's run with its pending carry folded in (C >= 2)
+    const uint2* ad = nullptr;
+    if (EXT && ext.add_digits) {
+      ad = reinterpret_cast<const uint2*>(ext.add_digits) + size_t(T) * tile + size_t(i1) * C;
+      if (ext.add_cbuf) {
+        const uint2 p0 = ad[0], p1 = ad[1];
+        addh[0] = p0.x; addh[1] = p0.y; addh[2] = p1.x; addh[3] = p1.y;
+        run_carry_in(pl, pl.SA[i1], T, carry_in_of(pl, ext.add_cbuf, T, i1), addh);
+      }
+    }
     for (uint32_t c = 0; c < C; ++c) {
       const uint32_t i2 = T * C + c;
       const P2 x = X[i1 * C + c];
       const uint32_t sb = pl.SB[2 * i2];
       uint32_t out[2];
+      uint32_t av[2] = {0, 0};
+      if (EXT && ad) {
+        if (ext.add_cbuf && c < 2) { av[0] = addh[2 * c]; av[1] = addh[2 * c + 1]; }
+        else { const uint2 q = ad[c]; av[0] = q.x; av[1] = q.y; }
+      }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         uint32_t width; bool wrap;
@@ -318,20 +347,64 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
         const uint64_t u = gf::mul(b ? x.b : x.a, wrap ? tai2[b] : tai[b]);
         const uint64_t mask = (uint64_t(1) << width) - 1;
         if (a == 1) {               // the common case (uniform): no 64-bit multiplies
-          const uint64_t r = u + carry;   // u < P, carry < 2^48: no wrap
+          const uint64_t r = u + carry + (EXT ? av[b] : 0u);   // u < 2^63 by the size rule (ibdwt.h:28-30), carry < 2^48, addend < 2^32
           out[b] = uint32_t(r & mask);
           carry = r >> width;
         } else {                    // adc_mul (marin.cl:194-201): digit first, so that everything stays in 64 bits
           const uint64_t dlo = u & mask, chi = u >> width;
-          const uint64_t r = dlo * a + carry;
+          const uint64_t r = dlo * a + carry + (EXT ? av[b] : 0u);
           out[b] = uint32_t(r & mask);
           carry = (r >> width) + chi * a;
         }
       }
       dg[i1 * C + c] = make_uint2(out[0], out[1]);
+      if (EXT && ext.digits2) reinterpret_cast<uint2*>(ext.digits2)[size_t(T) * tile + size_t(i1) * C + c] = make_uint2(out[0], out[1]);
     }
     cbuf[size_t(T) * M1 + i1] = carry;
+    if (EXT && ext.digits2) ext.cbuf2[size_t(T) * M1 + i1] = carry;
   }
+}
+
+// One thread per run: a, b (+ their pending carry words) -> sum and / or difference, each written to up to two
+// registers, with the run's carry-out word left pending (kernels.hpp LinArgs).  The difference is a - b + 2 Mp
+// digit by digit (neg2_mp4, marin.cl:246-256), so nothing goes negative: digits are below 2^width + a small excess.
+__global__ void __launch_bounds__(256) k_linear(DevPlan pl, LinArgs la) {
+  const uint32_t run = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t M1 = pl.M1, C = pl.C, NT = pl.M2 / C;
+  if (run >= M1 * NT) return;
+  const uint32_t T = run / M1, i1 = run - T * M1;
+  const size_t off = (size_t(T) * M1 + i1) * C * 2;
+  const uint32_t sa = pl.SA[i1];
+  uint64_t ca = la.ca ? carry_in_of(pl, la.ca, T, i1) : 0, cb = la.cb ? carry_in_of(pl, la.cb, T, i1) : 0;
+  uint64_t cs = 0, cd = 0;
+  const bool want_s = la.s1 != nullptr, want_d = la.d1 != nullptr;
+  for (uint32_t k = 0; k < 2 * C; ++k) {
+    uint32_t width; bool wrap;
+    digit_info(pl, sa, pl.SB[2 * (T * C) + k], width, wrap);
+    const uint64_t mask = (uint64_t(1) << width) - 1;
+    // inputs with their own (weak) carry-in: three masked digits, the rest stays on the fourth (adc4); runs of
+    // two digits (C = 1) take all of it on the second
+    uint64_t av = la.a[off + k], bv = la.b[off + k];
+    if (k < 3 && k + 1 < 2 * C) { av += ca; ca = av >> width; av &= mask; bv += cb; cb = bv >> width; bv &= mask; }
+    else if (k == 3 || k + 1 == 2 * C) { av += ca; ca = 0; bv += cb; cb = 0; }
+    if (want_s) {
+      const uint64_t v = av + bv + cs;
+      const uint32_t o = uint32_t(v & mask);
+      cs = v >> width;
+      la.s1[off + k] = o;
+      if (la.s2) la.s2[off + k] = o;
+    }
+    if (want_d) {
+      const uint64_t v = av + (4 * mask - bv) + cd;   // b's digit may exceed its width by a carry remainder: 4 Mp keeps it positive
+      const uint32_t o = uint32_t(v & mask);
+      cd = v >> width;
+      la.d1[off + k] = o;
+      if (la.d2) la.d2[off + k] = o;
+    }
+  }
+  const size_t ci = size_t(T) * M1 + i1;
+  if (want_s) { la.cs1[ci] = cs; if (la.s2) la.cs2[ci] = cs; }
+  if (want_d) { la.cd1[ci] = cd; if (la.d2) la.cd2[ci] = cd; }
 }
 
 
@@ -432,7 +505,17 @@ hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t*
 }
 hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s) {
   const size_t tile = size_t(pl.M1) * pl.C;
-  hipLaunchKernelGGL(k_back, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, W, digits, cbuf, a);
+  hipLaunchKernelGGL(k_back<false>, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, W, digits, cbuf, a, BackExt());
+  return hipGetLastError();
+}
+hipError_t launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s) {
+  const size_t tile = size_t(pl.M1) * pl.C;
+  hipLaunchKernelGGL(k_back<true>, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, W, digits, cbuf, a, x);
+  return hipGetLastError();
+}
+hipError_t launch_linear(const DevPlan& pl, const LinArgs& la, hipStream_t s) {
+  const size_t runs = size_t(pl.M1) * (pl.M2 / pl.C);
+  hipLaunchKernelGGL(k_linear, dim3((runs + 255) / 256), dim3(256), 0, s, pl, la);
   return hipGetLastError();
 }
 hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t* cbuf, hipStream_t s) {
@@ -454,7 +537,9 @@ hipError_t configure_kernels(size_t lds_front, size_t lds_mid) {
   if (lds_front > 48 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_front));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_back), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_front));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_back<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_front));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_back<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_front));
     if (e != hipSuccess) return e;
   }
   if (lds_mid > 48 * 1024)

@@ -19,6 +19,26 @@ struct DevPlan {
   uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs; bit 2: no issue-priority boost of the last half round
 };
 
+// Extras of a back sweep (the reference's fused carry variants, kernels/marin.cl:2160-2365):
+//   digits2 / cbuf2: a second register that receives the same result (square_mul_copy, mul_copy)
+//   add_digits (+ add_cbuf: its run carries when they are still pending): a residue added inside the carry chain (mul_add)
+struct BackExt {
+  uint32_t* digits2 = nullptr; uint64_t* cbuf2 = nullptr;
+  const uint32_t* add_digits = nullptr; const uint64_t* add_cbuf = nullptr;
+  bool any() const { return digits2 || add_digits; }
+};
+// Linear combinations of digit registers in one sweep (add / sub_reg / addsub / addsub_copy, marin.cl:1856-1947):
+// a, b with their pending run carries (null when none); outputs sum (s1, s2) and difference (d1, d2), each with the carry
+// words it leaves pending.  Digit outputs may alias the inputs; carry outputs must not alias ca / cb.
+struct LinArgs {
+  const uint32_t* a = nullptr; const uint64_t* ca = nullptr; const uint32_t* b = nullptr; const uint64_t* cb = nullptr;
+  uint32_t* s1 = nullptr; uint64_t* cs1 = nullptr; uint32_t* s2 = nullptr; uint64_t* cs2 = nullptr;
+  uint32_t* d1 = nullptr; uint64_t* cd1 = nullptr; uint32_t* d2 = nullptr; uint64_t* cd2 = nullptr;
+};
+hipError_t launch_linear(const DevPlan& pl, const LinArgs& la, hipStream_t s);
+hipError_t launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s);
+hipError_t v2_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s);
+
 hipError_t configure_kernels(size_t lds_front, size_t lds_mid);
 // cbuf_in (nullable, needs C >= 2): run carries left by the last back sweep, folded into the load
 hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint64_t* W, hipStream_t s);

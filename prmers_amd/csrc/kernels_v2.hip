@@ -470,10 +470,12 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
 // work buffer -> digits of the thread's R runs of tile T (inverse columns, unweight, x a, carry).
 // scale: extra field factor (1, or M2 when the input is a front image rather than a middle output).
 // carry0[d1]: carry entering run d1 (strong: propagated through the whole run); cout[d1]: carry leaving it.
-template <int R>
+// ADD: ad[d1][k] (the digits of another residue's runs, pending carries already folded in) join the carry chain (mul_add)
+template <int R, bool ADD = false>
 __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, uint32_t t, uint32_t lane, uint32_t wave,
                                           const uint64_t* __restrict__ Win, uint32_t a, uint64_t scale,
-                                          const uint64_t (&carry0)[R], uint32_t di, uint32_t (&dg)[R][16 / R], uint64_t (&cout)[R]) {
+                                          const uint64_t (&carry0)[R], uint32_t di, uint32_t (&dg)[R][16 / R], uint64_t (&cout)[R],
+                                          const uint32_t (*ad)[16 / R] = nullptr) {
   using S = ColShape<R>;
   constexpr int C = S::C, LC = S::LC;
   P2 x[8];
@@ -544,12 +546,12 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
       const uint64_t u = (k & 1) ? gf::mul(v.b, wrap ? tai2_o : tai_o) : gf::mul(v.a, wrap ? tai2_e : tai_e);   // wrapped exponents: weight was halved
       const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
       if (a == 1) {               // the common case (uniform): no 64-bit multiplies
-        const uint64_t r = u + carry;                      // u < P, carry < 2^48: no wrap
+        const uint64_t r = u + carry + (ADD ? ad[d1][k] : 0u);   // u < 2^63 by the size rule (ibdwt.h:28-30), carry < 2^48
         dg[d1][k] = __builtin_amdgcn_ubfe(uint32_t(r), 0u, width);   // width < 32: one bit-field extract
         carry = r >> width;
       } else {
         const uint64_t dlo = u & mask, chi = u >> width;
-        const uint64_t r = dlo * a + carry;
+        const uint64_t r = dlo * a + carry + (ADD ? ad[d1][k] : 0u);
         dg[d1][k] = uint32_t(r & mask);
         carry = (r >> width) + chi * a;
       }
@@ -613,6 +615,37 @@ __global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __
     const uint32_t i1 = 512 * d1 + t;
     store_run<R>(digits, T, i1, dg[d1]);
     cbuf[size_t(T) * (512 * R) + i1] = cout[d1];
+  }
+}
+
+// back sweep with extras (kernels.hpp BackExt): a second destination register and / or an addend in the carry chain
+template <int R>
+__global__ void __launch_bounds__(512, 4) k3_cols_ext(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+                                                      uint64_t* __restrict__ cbuf, uint32_t a, BackExt ext) {
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, blockIdx.x, gridDim.x);
+  boost_if_late(pl.boost_tiles);
+  uint32_t dg[R][16 / R], ad[R][16 / R];
+  uint64_t cout[R], zero[R];
+  const uint32_t di = pl.DI[size_t(T) * 512 + t];
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) {
+    zero[d1] = 0;
+#pragma unroll
+    for (int k = 0; k < 16 / R; ++k) ad[d1][k] = 0;
+    if (ext.add_digits) {
+      const uint32_t i1 = 512 * d1 + t;
+      load_run<R>(ext.add_digits, T, i1, ad[d1]);
+      if (ext.add_cbuf) apply_carry_in<16 / R>(pl, di, d1, carry_in_of(pl, ext.add_cbuf, T, i1), ad[d1]);
+    }
+  }
+  back_tile<R, true>(pl, X, T, t, lane, wave, Win, a, 1, zero, di, dg, cout, ad);
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) {
+    const uint32_t i1 = 512 * d1 + t;
+    store_run<R>(digits, T, i1, dg[d1]);
+    cbuf[size_t(T) * (512 * R) + i1] = cout[d1];
+    if (ext.digits2) { store_run<R>(ext.digits2, T, i1, dg[d1]); ext.cbuf2[size_t(T) * (512 * R) + i1] = cout[d1]; }
   }
 }
 
@@ -816,6 +849,7 @@ hipError_t v2_configure() {
   MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes)
   MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
+  MI355_SET_LDS(v2::k3_cols_ext<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols_ext<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols_ext<4>, v2::kLdsBytes)
 #if defined(MI355_EXPERIMENTAL)
   MI355_SET_LDS(v2::k3k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k31_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<4>, v2::kLdsBytes)
@@ -848,6 +882,15 @@ hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits
     case 512: hipLaunchKernelGGL(v2::k3_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
     case 1024: hipLaunchKernelGGL(v2::k3_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
     default: hipLaunchKernelGGL(v2::k3_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
+  }
+  return hipGetLastError();
+}
+hipError_t v2_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s) {
+  const dim3 grid(pl.M2 / pl.C), block(512);
+  switch (pl.M1) {
+    case 512: hipLaunchKernelGGL(v2::k3_cols_ext<1>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, x); break;
+    case 1024: hipLaunchKernelGGL(v2::k3_cols_ext<2>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, x); break;
+    default: hipLaunchKernelGGL(v2::k3_cols_ext<4>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, x); break;
   }
   return hipGetLastError();
 }

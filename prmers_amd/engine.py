@@ -69,6 +69,11 @@ def load_library():
         "mi355_engine_kernel_name": (C.c_char_p, [vp, sz]),
         "mi355_engine_algorithmic_bytes": (sz, [vp]),
         "mi355_engine_selftest": (C.c_int, [sz]),
+        "mi355_engine_addsub": (C.c_int, [vp, sz, sz, sz, sz]),
+        "mi355_engine_addsub_copy": (C.c_int, [vp, sz, sz, sz, sz, sz, sz]),
+        "mi355_engine_mul_add": (C.c_int, [vp, sz, sz, sz, u32]),
+        "mi355_engine_square_mul_copy": (C.c_int, [vp, sz, sz, u32]),
+        "mi355_engine_mul_copy": (C.c_int, [vp, sz, sz, sz, u32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -87,6 +92,7 @@ EXPORTS = [
     "mi355_engine_set_data", "mi355_engine_checkpoint_size", "mi355_engine_get_checkpoint",
     "mi355_engine_set_checkpoint", "mi355_engine_time_square_mul", "mi355_engine_kernel_count",
     "mi355_engine_kernel_name", "mi355_engine_algorithmic_bytes", "mi355_engine_selftest",
+    "mi355_engine_addsub", "mi355_engine_addsub_copy", "mi355_engine_mul_add", "mi355_engine_square_mul_copy", "mi355_engine_mul_copy",
 ]
 
 
@@ -147,6 +153,13 @@ class Engine:
     def sub(self, src, a): self._ok(self.L.mi355_engine_sub_u32(self.h, src, a))
     def add(self, dst, src): self._ok(self.L.mi355_engine_add(self.h, dst, src))
     def sub_reg(self, dst, src): self._ok(self.L.mi355_engine_sub_reg(self.h, dst, src))
+
+    # fused variants (engine.h:65-131): one sweep each
+    def addsub(self, sum_out, diff_out, a, b): self._ok(self.L.mi355_engine_addsub(self.h, sum_out, diff_out, a, b))
+    def addsub_copy(self, s, d, s_copy, d_copy, a, b): self._ok(self.L.mi355_engine_addsub_copy(self.h, s, d, s_copy, d_copy, a, b))
+    def mul_add(self, dst, mul_src, add_src, a=1): self._ok(self.L.mi355_engine_mul_add(self.h, dst, mul_src, add_src, a))
+    def square_mul_copy(self, src, dst_copy, a=1): self._ok(self.L.mi355_engine_square_mul_copy(self.h, src, dst_copy, a))
+    def mul_copy(self, dst, src, dst_copy, a=1): self._ok(self.L.mi355_engine_mul_copy(self.h, dst, src, dst_copy, a))
 
     def is_equal(self, lhs, rhs):
         out = C.c_int(0)
