@@ -4,8 +4,14 @@
 // R0 = x, R1 = Gerbicz accumulator d, R2 = multiplicand of x, R3 = check register, R4/R5 = last good
 // (x, d), RBASE/RTMP = 3 and its multiplicand; check every `checklevel` blocks of B = floor(sqrt(p)).
 //
+// Caller-side files as the reference leaves them (include/mi355/caller_formats.h): -worktodo takes the first PRP= / Test= entry
+// and rotates the file when the test is complete; -ckpt DIR resumes from / saves version-2 checkpoints (every -backup N
+// iterations and at the end of a partial run); -proof POWER writes the residues a proof of that power needs under
+// <p>/proof/; -json FILE appends the result line.
+//
 //   g++ -std=c++17 -O2 -Iinclude examples/prp_cli.cpp -ldl -lgmp -o mi355_prp
-//   ./mi355_prp <p> [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-lib path/to/libmi355_engine.so]
+//   ./mi355_prp <p> | -worktodo FILE  [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER]
+//               [-json FILE] [-lib path/to/libmi355_engine.so]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,18 +19,40 @@
 #include <memory>
 #include <string>
 
+#include "mi355/caller_formats.h"
 #include "mi355/engine_hip.h"
 
+namespace fmt = mi355::formats;
+
+static std::vector<uint32_t> residue_words(engine* eng, size_t reg, uint32_t p) {
+  engine::digit d(eng, reg);
+  std::vector<uint64_t> v(d.get_size());
+  for (size_t i = 0; i < v.size(); ++i) v[i] = (uint64_t(d.width(i)) << 32) | uint64_t(d.val(i));
+  return fmt::pack_words(v, p);
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: %s <p> [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-lib so]\n", argv[0]); return 2; }
-  const uint32_t p = uint32_t(std::strtoul(argv[1], nullptr, 10));
-  bool ll = false; uint64_t erroriter = 0, checklevel = 0, maxiters = 0; std::string lib;
-  for (int i = 2; i < argc; ++i) {
+  if (argc < 2) { std::fprintf(stderr, "usage: %s <p> | -worktodo FILE [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER] [-json FILE] [-lib so]\n", argv[0]); return 2; }
+  uint32_t p = uint32_t(std::strtoul(argv[1], nullptr, 10));
+  bool ll = false; uint64_t erroriter = 0, checklevel = 0, maxiters = 0, backup = 0; std::string lib, worktodo, ckpt_dir, json_file; uint32_t proof_power = 0;
+  fmt::WorkEntry entry;
+  for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "-ll")) ll = true;
+    else if (!std::strcmp(argv[i], "-worktodo") && i + 1 < argc) worktodo = argv[++i];
+    else if (!std::strcmp(argv[i], "-ckpt") && i + 1 < argc) ckpt_dir = argv[++i];
+    else if (!std::strcmp(argv[i], "-backup") && i + 1 < argc) backup = std::strtoull(argv[++i], nullptr, 10);
+    else if (!std::strcmp(argv[i], "-proof") && i + 1 < argc) proof_power = uint32_t(std::strtoul(argv[++i], nullptr, 10));
+    else if (!std::strcmp(argv[i], "-json") && i + 1 < argc) json_file = argv[++i];
     else if (!std::strcmp(argv[i], "-erroriter") && i + 1 < argc) erroriter = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "-checklevel") && i + 1 < argc) checklevel = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "-maxiters") && i + 1 < argc) maxiters = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "-lib") && i + 1 < argc) lib = argv[++i];
+  }
+  if (!worktodo.empty()) {
+    entry = fmt::first_worktodo_entry(worktodo);
+    if (!entry.valid) { std::fprintf(stderr, "Error: no PRP= / Test= entry in %s\n", worktodo.c_str()); return 2; }
+    p = entry.exponent; ll = entry.ll;
+    std::printf("worktodo: %s\n", entry.raw.c_str());
   }
   try {
     std::unique_ptr<engine> eng(new engine_hip(p, 8, 0, false, lib));
@@ -39,9 +67,21 @@ int main(int argc, char** argv) {
     if (level == 0) level = 1;
     uint64_t itersave = 0, jsave = total - 1, checkpass = 0, errors = 0, done = 0;
     bool errordone = false, complete = true;
-    mpz_t z0, z1; mpz_inits(z0, z1, nullptr);
-    for (uint64_t iter = 0, j = total - 1; iter < total; ++iter, --j) {
+    // resume (RunPrpOrLlMarin.cpp:212-236): the checkpoint holds every register, the callers rebuild their multiplicands
+    uint32_t ri = 0; double elapsed0 = 0;
+    const std::string ckpt = ckpt_dir.empty() ? std::string() : fmt::checkpoint_name(p, ll, ckpt_dir);
+    if (!ckpt.empty()) {
+      int rc = fmt::load_checkpoint(ckpt, *eng, p, ll, ri, elapsed0);
+      if (rc != 0) rc = fmt::load_checkpoint(ckpt + ".old", *eng, p, ll, ri, elapsed0);
+      if (rc == 0) { std::printf("Resuming from a checkpoint at iteration %u\n", ri); eng->set(RBASE, 3); eng->set_multiplicand(RTMP, RBASE); eng->copy(R4, R0); eng->copy(R5, R1); }
+      else ri = 0;
+    }
+    std::unique_ptr<fmt::ProofPoints> proof;
+    if (proof_power && !ll) proof.reset(new fmt::ProofPoints(p, proof_power));
+    uint64_t last_iter = ri;
+    for (uint64_t iter = ri, j = total - ri - 1; iter < total; ++iter, --j) {
       if (maxiters && done >= maxiters) { complete = false; break; }
+      last_iter = iter + 1;
       eng->square_mul(R0);
       if (ll) eng->sub(R0, 2);
       ++done;
@@ -55,12 +95,13 @@ int main(int argc, char** argv) {
           for (uint64_t z = 0; z < (B > modB ? B - modB - 1 : 0); ++z) eng->square_mul(R3);
           if (p % B == 0) eng->mul(R3, RTMP); else eng->square_mul(R3, 3);
           for (uint64_t z = 0; z < modB; ++z) eng->square_mul(R3);
-          eng->get_mpz(z0, R3); eng->get_mpz(z1, R1);
-          if (mpz_cmp(z0, z1) != 0) {
+          // the reference compares two mpz read-backs (RunPrpOrLlMarin.cpp:363-366); is_equal does it on the device
+          if (!eng->is_equal(R3, R1)) {
             std::printf("[Gerbicz Li] Mismatch \n[Gerbicz Li] Check FAILED! iter=%llu\n[Gerbicz Li] Restore iter=%llu (j=%llu)\n",
                         (unsigned long long)(iter + 1), (unsigned long long)itersave, (unsigned long long)jsave);
             j = jsave; iter = itersave;
             if (iter == 0) { iter = iter - 1; j = j + 1; }
+            checkpass = 0;   // RunPrpOrLlMarin.cpp:391
             ++errors;
             eng->copy(R0, R4); eng->copy(R1, R5);
           } else {
@@ -70,13 +111,29 @@ int main(int argc, char** argv) {
           }
         }
       }
+      // proof residues (ProofManagerMarin::checkpointMarin, ProofManagerMarin.cpp:84-120) and periodic backups (:430-447)
+      if (proof && proof->should_checkpoint(uint32_t(iter + 1))) proof->save(uint32_t(iter + 1), residue_words(eng.get(), R0, p));
+      if (!ckpt.empty() && backup && done % backup == 0) fmt::save_checkpoint(ckpt, *eng, p, ll, uint32_t(iter + 1), elapsed0);
     }
-    mpz_clears(z0, z1, nullptr);
+    if (!ckpt.empty() && !complete) fmt::save_checkpoint(ckpt, *eng, p, ll, uint32_t(last_iter - (maxiters && done >= maxiters ? 1 : 0)), elapsed0);
     engine::digit d(eng.get(), R0);
     const bool prime = ll ? (d.equal_to(0) || d.equal_to_Mp()) : d.equal_to(9);
     std::printf("M%u %s: %s  res64(raw)=%016llX  gerbicz_errors=%llu  n=%zu\n", p, ll ? "LL" : "PRP-3",
                 complete ? (prime ? "probably prime" : "composite") : "partial run",
                 (unsigned long long)d.res64(), (unsigned long long)errors, eng->get_size());
+    if (complete) {
+      std::vector<uint32_t> W = residue_words(eng.get(), R0, p);
+      if (!ll && p % 6 != 0) { uint32_t two_p_mod9 = 1; for (uint32_t i = 0; i < p % 6; ++i) two_p_mod9 = two_p_mod9 * 2 % 9; if (two_p_mod9 != 1) fmt::prp3_div9(p, W); }
+      fmt::ResultInfo r; r.exponent = p; r.ll = ll; r.is_prime = prime; r.res64 = fmt::res64_hex(W); r.res2048 = fmt::res2048_hex(W);
+      r.gerbicz_errors = unsigned(errors); r.fft_length = unsigned(eng->get_size()); r.aid = entry.aid;
+      const std::string line = fmt::result_json(r);
+      std::printf("%s\n", line.c_str());
+      if (!json_file.empty()) { std::ofstream f(json_file, std::ios::app); f << line << "\n"; }
+      if (!worktodo.empty()) {
+        const bool more = fmt::rotate_worktodo(worktodo, "worktodo_save.txt");
+        std::printf("Entry removed from %s and saved to worktodo_save.txt%s\n", worktodo.c_str(), more ? "; more entries remain" : "; no more entries");
+      }
+    }
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "Error: %s\n", e.what());

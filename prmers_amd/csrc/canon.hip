@@ -131,6 +131,19 @@ __global__ void __launch_bounds__(256) k_apply(CanonGeom g, const uint32_t* __re
   }
 }
 
+// One local carry pass in place of layout (tile-major in, tile-major out): d'[j] = (d[j] mod 2^w_j) + (d[j-1] >> w_{j-1}).
+// For plans whose runs are only two digits long (C = 1): the weak carry of a back sweep then leaves up to log2(n) - 2
+// excess bits on a run's second digit, too much for the next squaring once n >= 2^19; one pass brings it down to
+// log2(n) - 2 - w bits (the reference spreads a work-group's last carry over four digits, adc4 marin.cl:203-212).
+__global__ void __launch_bounds__(256) k_relax(CanonGeom g, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= g.n) return;
+  const uint32_t jp = j ? j - 1 : g.n - 1;
+  const uint64_t o0 = ceil_pj_n(g, jp), o1 = ceil_pj_n(g, uint64_t(jp) + 1), o2 = ceil_pj_n(g, uint64_t(j) + 1);
+  const uint32_t wp = uint32_t(o1 - o0), w = uint32_t(o2 - (j ? o1 : 0));
+  out[pos_of(g, j)] = (in[pos_of(g, j)] & ((1u << w) - 1u)) + (in[pos_of(g, jp)] >> wp);
+}
+
 // natural order -> tile-major (set_digits / set_words without the host-side re-tiling)
 __global__ void __launch_bounds__(256) k_scatter(CanonGeom g, const uint32_t* __restrict__ nat, uint32_t* __restrict__ digits) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -191,6 +204,10 @@ hipError_t canon_launch(const DevPlan& pl, uint32_t p, const uint32_t* digits, u
 uint32_t* canon_flags(const DevPlan& pl, uint32_t* scratch) {
   const size_t nb = (size_t(pl.n) + kBlockDigits - 1) / kBlockDigits;
   return scratch + 2 * size_t(pl.n) + 2 * nb;
+}
+hipError_t canon_relax(const DevPlan& pl, uint32_t p, const uint32_t* in, uint32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_relax, dim3((pl.n + 255) / 256), dim3(256), 0, s, geom_of(pl, p), in, out);
+  return hipGetLastError();
 }
 hipError_t canon_scatter(const DevPlan& pl, uint32_t p, const uint32_t* nat, uint32_t* digits, hipStream_t s) {
   hipLaunchKernelGGL(k_scatter, dim3((pl.n + 255) / 256), dim3(256), 0, s, geom_of(pl, p), nat, digits);

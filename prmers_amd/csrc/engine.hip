@@ -215,6 +215,23 @@ void Engine::normalize(size_t r) {
   }
 }
 
+// Runs of two digits (C = 1): the run carries go into the digits at once.  A carry word has about w + log2(n) bits (the
+// convolution sums of unsigned digits are ~ n 2^(2w-2)); its first digit absorbs w of them and the rest lands on the
+// run's second digit, log2(n) - 2 (+ log2 a) bits above its width -- too much for the next squaring once that exceeds w.
+// Local carry passes (canon.hip k_relax) take w bits off per pass; as many as it takes to get below the width follow.
+void Engine::carry_fix_now(size_t r) {
+  HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_));
+  pending_carry_[r] = 0;
+  if (pl_.C >= 2) return;
+  int excess = ilog2(pl_.n) + 1 + 4 - 2;   // log2(n) rounded up, factor a up to 15
+  const int w = int(pl_.q);                 // the narrower digit width
+  while (excess > w - 2) {
+    HIPCHK(canon_relax(dp_, pl_.p, digits(r), reinterpret_cast<uint32_t*>(work()), stream_));
+    swap_with_work(r);
+    excess -= w;
+  }
+}
+
 void Engine::run_front(size_t r) {
   if (v2cols_) {
     HIPCHK(v2_launch_front(dp_, digits(r), pending_carry_[r] ? cbuf(r) : nullptr, pending_sub_[r], work(), stream_));
@@ -240,7 +257,7 @@ void Engine::run_back(size_t r, uint32_t a) {
   } else {
     HIPCHK(launch_back(dp_, work(), digits(r), cbuf(r), a, stream_));
     if (pl_.C >= 2) pending_carry_[r] = 1;   // the generic front folds the run carries in as well
-    else { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }
+    else carry_fix_now(r);
   }
   pending_sub_[r] = 0;
 }
@@ -492,7 +509,7 @@ void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
     HIPCHK(launch_back(dp_, work(), digits(r), cbuf(r), a, stream_));
     if (ev) HIPCHK(hipEventRecord(ev[3], stream_));
     if (pl_.C >= 2) pending_carry_[r] = 1;
-    else { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }
+    else carry_fix_now(r);
     if (ev) HIPCHK(hipEventRecord(ev[4], stream_));
   }
   pending_sub_[r] = 0;
@@ -580,7 +597,7 @@ void Engine::linear(long s1, long s2, long d1, long d2, size_t a, size_t b) {
       const size_t r = size_t(outs[i]);
       adopt_cbuf(r, fresh[i]);
       kind_[r] = kDigits; pending_carry_[r] = 1; pending_sub_[r] = 0;
-      if (pl_.C < 2) { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }   // runs of two digits: no deferred fold
+      if (pl_.C < 2) carry_fix_now(r);   // runs of two digits: no deferred fold
     }
 }
 
@@ -617,7 +634,7 @@ void Engine::back_ext(size_t dst, uint32_t a, long copy_to, long add_src) {
   for (int i = 0; i < (x.digits2 ? 2 : 1); ++i) {
     const size_t r = outs[i];
     kind_[r] = kDigits; pending_sub_[r] = 0; pending_carry_[r] = 1;
-    if (!v2cols_ && pl_.C < 2) { HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_)); pending_carry_[r] = 0; }
+    if (!v2cols_ && pl_.C < 2) carry_fix_now(r);
   }
 }
 

@@ -88,6 +88,7 @@ class Engine {
   void linear(long s1, long s2, long d1, long d2, size_t a, size_t b);
   void back_ext(size_t dst, uint32_t a, long copy_to, long add_src);
   void normalize(size_t r);          // apply deferred run carries / small subtraction
+  void carry_fix_now(size_t r);      // run carries into the digits right away (plans with runs of two digits cannot defer them)
   void run_front(size_t r);          // digits(r) -> work_, consuming pending state when the kernel can
   void run_middle(const uint64_t* in, const uint64_t* y, uint64_t* out, int mode, uint32_t sub);
   void run_back(size_t r, uint32_t a);

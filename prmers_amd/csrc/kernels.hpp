@@ -69,6 +69,7 @@ size_t canon_scratch_words(const DevPlan& pl);
 hipError_t canon_launch(const DevPlan& pl, uint32_t p, const uint32_t* digits, uint32_t* out, uint32_t* scratch, hipStream_t s);
 uint32_t* canon_flags(const DevPlan& pl, uint32_t* scratch);
 hipError_t canon_compare(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* diff_flag, hipStream_t s);
+hipError_t canon_relax(const DevPlan& pl, uint32_t p, const uint32_t* in, uint32_t* out, hipStream_t s);   // one local carry pass, tile-major both sides
 hipError_t canon_scatter(const DevPlan& pl, uint32_t p, const uint32_t* nat, uint32_t* digits, hipStream_t s);
 hipError_t canon_set_small(const DevPlan& pl, uint32_t p, uint32_t* digits, uint32_t value, hipStream_t s);
 

@@ -142,7 +142,8 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   pl.M1 = uint32_t(pl.m / pl.M2);
   pl.L1 = pl.M1 / pl.r5;
   pl.logL1 = uint32_t(ilog2(pl.L1));
-  if (pl.M1 > 2560) throw std::runtime_error("transform size not supported yet (n > 5*2^23)");
+  // columns live in LDS on the generic kernel set: M1 x C pairs of 16 bytes within the 160 KiB of a CU
+  if (size_t(pl.M1) * 16 > 160 * 1024) throw std::runtime_error("transform size not supported yet (n > 5*2^25: columns of more than 10240 pairs)");
 
   // tile: up to 4096 pairs (64 KiB), runs of at most 16 pairs (256 B of the work buffer);
   // grow to 8192 pairs (128 KiB) when that is what C >= 4 needs
@@ -151,9 +152,12 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   // (not for columns of 2048: the register-resident column kernels take them as 4096-pair tiles with C = 2)
   while (C < 4 && C * 2 <= pl.M2 && size_t(pl.M1) * (C * 2) <= 8192 && !(pl.r5 == 1 && pl.M1 == 2048)) C *= 2;
   while (C > 4 && pl.M2 / C < 256) C /= 2;   // mid-size transforms: enough tiles to fill 256 CUs
+  // runs of two digits cannot absorb the run carries of a large transform (they leave log2(n) - 2 excess bits on a digit):
+  // take C = 2 wherever the tile still fits the 160 KiB of LDS; beyond that the engine adds a local carry pass
+  if (C == 1 && pl.M2 >= 2 && size_t(pl.M1) * 2 * 16 <= 160 * 1024 && pl.n >= (size_t(1) << 19)) C = 2;
   if (want_c > 0) {
     C = uint32_t(want_c);
-    if ((C & (C - 1)) != 0 || C > pl.M2 || size_t(pl.M1) * C > 8192) throw std::runtime_error("bad c in plan spec");
+    if ((C & (C - 1)) != 0 || C > pl.M2 || size_t(pl.M1) * C > 10240) throw std::runtime_error("bad c in plan spec");
   }
   pl.C = C;
   pl.lds_front = size_t(pl.M1) * pl.C * 16;

@@ -334,9 +334,45 @@ def test_largest_supported_transforms(p, n):
 
 
 def test_unsupported_transform_size_is_refused():
-    """n > 5*2^23 needs a third transform level this round does not have: creation fails loudly."""
+    """n = 5*2^26 (the reference's largest schedule entry, engine_gpu.h:1624) needs columns of 20480 pairs, more than a CU's
+    LDS holds: creation fails loudly."""
     with pytest.raises(Exception, match="not supported"):
-        Engine(800000011, 2)
+        Engine(4000000007, 2)
+
+
+@pytest.mark.parametrize("p,n,plan", [(800000011, 1 << 26, "m1=4096:m2=8192:c=2"), (1300000003, 5 << 24, "m1=5120:m2=8192:c=2"),
+                                      (1800000011, 5 << 25, "m1=10240:m2=8192:c=1")])
+def test_largest_transform_sizes(p, n, plan):
+    """The reference's schedule entries above 5*2^23 (include/marin/engine_gpu.h:1598,1622-1623): 2^26, 5*2^24, 5*2^25 --
+    columns of 4096 / 5120 / 10240 pairs in LDS (generic set), rows of 8192 on the register-resident kernel."""
+    from prmers_amd import resolve_plan
+    assert resolve_plan(p).endswith(plan)
+    o = orc.Oracle(p, 2)
+    assert o.n == n
+    rng = np.random.default_rng(p)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 2) as e:
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        e.square_mul(0); o.square_mul(0)
+        e.square_mul(0, 3); e.sub(0, 2); o.square_mul(0, 3); o.sub(0, 2)
+        e.square_mul(0); o.square_mul(0)                          # consumes the weakly carried digits of the step before
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert e.res64(0) == o.res64(0)
+        e.copy(1, 0)
+        assert e.is_equal(0, 1)
+    # x_0 = 3, x_{i+1} = x_i^2: GMP pins (tests/golden/huge_p_pins.json, made by make_huge_p_pins.py), no oracle involved
+    import hashlib
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "huge_p_pins.json")))["pins"][str(p)]
+    with Engine(p, 2) as e:
+        e.set(0, 3)
+        it = 0
+        for pin in pins:
+            while it < pin["iteration"]:
+                e.square_mul(0); it += 1
+            wds = e.words(0)
+            assert "%016X" % (int(wds[0]) | (int(wds[1]) << 32)) == pin["res64"], (p, it)
+            assert hashlib.sha256(wds.astype("<u4").tobytes()).hexdigest() == pin["sha256_words"], (p, it)
 
 
 @pytest.mark.parametrize("p,n,m1", [(57885161, 1 << 22, 512), (250000013, 1 << 24, 2048)])

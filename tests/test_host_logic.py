@@ -213,3 +213,94 @@ def test_alias_shim_exports_the_reference_plugin_abi():
                                 for n in AEVUM_NAMES if n not in ("create",)) + "int main(void) { return 0; }\n")
             subprocess.check_call(["gcc", "-fsyntax-only", "-Werror=incompatible-pointer-types", "-I/root/reference/third_party/aevum/src",
                                    "-I" + os.path.join(ROOT, "include"), src])
+
+
+def test_cpp_caller_formats_match_the_python_mirror_and_known_answers(tmp_path):
+    """include/mi355/caller_formats.h (C++ side of SURVEY.md 8f N3: checkpoint file v2 + CRC, worktodo entries and rotation,
+    result JSON, proof checkpoints, residue words) against prmers_amd/prp.py -- itself pinned by the reference's golden
+    vectors (tests/test_prp_driver.py) -- and against known answers."""
+    import json
+    import numpy as np
+    from prmers_amd import prp
+    exe = str(tmp_path / "t_formats")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "test_caller_formats.cpp")])
+    work = tmp_path / "w"
+    work.mkdir()
+    out = subprocess.run([exe, str(work)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout)
+    assert r["crc_check"] == "CBF43926"                      # CRC-32 of "123456789"
+    # words / type-1 residue / hex: the same digit vector through the Python mirror
+    w = [16] * 7 + [15]
+    d = np.array([(w[i] << 32) | ((0x9e37 * (i + 3) + 77) & ((1 << w[i]) - 1)) for i in range(8)], dtype=np.uint64)
+    W = prp.pack_words(d, 127)
+    assert r["res64_raw"] == prp.format_res64(W)
+    W9 = prp.prp3_div9(127, W)
+    assert r["res64_div9"] == prp.format_res64(W9) and r["res2048_div9"] == prp.format_res2048(W9)
+    x = sum(int(v & 0xFFFFFFFF) << (16 * i) for i, v in enumerate(d)) % ((1 << 127) - 1)
+    assert int(r["res64_div9"], 16) == (x * pow(9, -1, (1 << 127) - 1)) % ((1 << 127) - 1) & ((1 << 64) - 1)
+    # checkpoint file
+    c = r["ckpt"]
+    assert c == {"saved": 1, "load": 0, "iteration": 2345, "elapsed": 6.5, "same": 1, "old": 0, "old_iteration": 1234, "wrong_mode": -3,
+                 "wrong_exponent": -2, "corrupt": -2, "missing": -1, "name_ll": "llunsafe_m_607.ckpt"}
+    # worktodo lines: same verdicts as the Python parser
+    lines = ["PRP=1,2,136279841,-1", "PRP=N/A,1,2,9941,-1,75,0", "PRPDC=0123456789ABCDEF0123456789abcdef,1,2,521,-1", "Test=607",
+             "DoubleCheck=AID,1279,70,1", "Pfactor=1,2,999,-1,70,2", "# PRP=1,2,127,-1", "", "PRP=1,3,127,-1", "Test=N/A,2203,75,1"]
+    for line, got in zip(lines, r["worktodo"]):
+        want = prp.parse_worktodo_line(line)
+        assert bool(got[0]) == (want is not None), line
+        if want:
+            assert (("ll" if got[1] else "prp"), got[2]) == want, line
+    assert r["worktodo"][2][3] == "0123456789ABCDEF0123456789abcdef"
+    assert r["rotate"] == {"removed": 1, "more1": 1, "next": 607, "more2": 1, "more3": 0, "saved": "PRP=1,2,127,-1|# note|Test=607|"}
+    # result lines: key for key what the Python mirror prints
+    res = {"exponent": 100003, "mode": "prp", "is_prime": False, "res64": "1CF45E9503C71FD6", "res2048": "ab", "gerbicz_errors": 1}
+    want = json.loads(prp.result_json(res, 8192, program_version="v", user="u", computer="c", aid="a", timestamp="t"))
+    got = json.loads(r["json_prp"])
+    assert list(got.keys())[:9] == ["status", "exponent", "worktype", "res64", "res2048", "residue-type", "errors", "shift-count", "fft-length"]
+    for k in ("status", "exponent", "worktype", "res64", "res2048", "residue-type", "errors", "shift-count", "fft-length", "user", "computer", "aid", "timestamp"):
+        assert got[k] == want[k], k
+    ll = json.loads(r["json_ll"])
+    assert ll["status"] == "P" and ll["worktype"] == "LL" and "res2048" not in ll and "user" not in ll
+    # proof points: ProofSetMarin.cpp:64-84 restated independently
+    E, power = 9941, 3
+    pts, span = [0], (E + 1) // 2
+    for _ in range(power):
+        pts += [q + span for q in pts]
+        span = (span + 1) // 2
+    pts[0] = E
+    assert r["proof_points"] == sorted(pts) and len(pts) == 1 << power and r["proof_points"][-1] == E
+    assert r["proof"] == {"saved": 1, "other_iteration_ignored": 1, "round_trip": 1, "corruption_caught": 1, "valid_to_before": 1,
+                          "file": "9941/proof/%d" % sorted(pts)[2]}
+
+
+@pytest.mark.gpu
+def test_cpp_driver_worktodo_checkpoint_proof_and_json_on_gpu(tmp_path):
+    """examples/prp_cli.cpp with the caller-side formats (include/mi355/caller_formats.h): a worktodo entry is run in two
+    slices through a version-2 checkpoint, leaves the proof residues, the reference's golden result line of M100003
+    (unit_tests.sh:140-141) and a rotated worktodo."""
+    import json
+    from prmers_amd import engine as E
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")))
+    exe = _build_cli(str(tmp_path))
+    wt = tmp_path / "worktodo.txt"
+    wt.write_text("PRP=0123456789ABCDEF0123456789ABCDEF,1,2,100003,-1,75,0\nTest=607\n")
+    run = lambda *a: subprocess.run([exe, *a, "-lib", E.LIB_PATH], capture_output=True, text=True, cwd=str(tmp_path))   # noqa: E731
+    o1 = run("-worktodo", str(wt), "-ckpt", str(tmp_path), "-proof", "2", "-maxiters", "60000", "-json", "results.json.txt")
+    assert o1.returncode == 0 and "partial run" in o1.stdout, o1.stdout + o1.stderr
+    assert (tmp_path / "m_100003.ckpt").exists() and wt.read_text().startswith("PRP=")          # not finished: nothing rotated
+    o2 = run("-worktodo", str(wt), "-ckpt", str(tmp_path), "-proof", "2", "-json", "results.json.txt")
+    assert o2.returncode == 0 and "Resuming from a checkpoint" in o2.stdout, o2.stdout + o2.stderr
+    line = json.loads((tmp_path / "results.json.txt").read_text().splitlines()[-1])
+    m = gold["m100003"]
+    assert line["exponent"] == 100003 and line["worktype"] == "PRP-3" and line["status"] == "C"
+    assert line["res64"] == "1CF45E9503C71FD6" and line["residue-type"] == 1 and line["errors"] == {"gerbicz": 0}
+    assert line["aid"] == "0123456789ABCDEF0123456789ABCDEF" and line["fft-length"] == 8192
+    assert line["res64"] == m["res64"] and line["res2048"] == m["res2048"].lower()
+    assert wt.read_text() == "Test=607\n" and "100003" in (tmp_path / "worktodo_save.txt").read_text()
+    pts = sorted(int(f.name) for f in (tmp_path / "100003" / "proof").iterdir())
+    assert pts == [25001, 50002, 75003, 100003]            # the 2^2 points of ProofSetMarin.cpp:64-84 for E = 100003
+    assert (tmp_path / "100003" / "proof" / "25001").stat().st_size == 4 + 4 * ((100003 + 31) // 32)
+    o3 = run("-worktodo", str(wt))
+    assert "probably prime" in o3.stdout and wt.read_text() == ""
