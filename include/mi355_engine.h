@@ -103,6 +103,17 @@ MI355_ENGINE_API int mi355_engine_selftest(size_t device);
 /* algorithmic bytes one squaring moves (48 * n) */
 MI355_ENGINE_API size_t mi355_engine_algorithmic_bytes(mi355_engine_handle handle);
 
+
+/* ---- second field family, first slice ----
+   The fused unweight + Garner + carry sweep of the paired-NTT squaring over GF(M61^2) x GF(M31^2) (the reference's FFT3161 carry
+   kernel, third_party/aevum/src/cl/carry.cl:506-588): in61 / in31 = the two residues of every scaled, still weighted convolution
+   coefficient in logical digit order (transform_words = odd_radix * 2^k of them, odd_radix in {1, 3, 9}); digits_out = the digits in
+   base 2^width after the run-wise carry (widths reach 39 bits: plain u64 values); residual_out = ceil(words / 8) carries (0 or a few
+   units) still to be added in front of each following run of 8 digits (cyclically).  Host buffers in and out; kernel_ms (may be NULL)
+   receives the duration of the sweep. */
+MI355_ENGINE_API int mi355_crt_carry(uint32_t exponent, size_t transform_words, uint32_t odd_radix, uint32_t factor, const uint64_t* in61,
+                                     const uint32_t* in31, uint64_t* digits_out, uint64_t* residual_out, size_t device, double* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

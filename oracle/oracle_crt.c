@@ -108,7 +108,8 @@ typedef struct orcc_ctx {
   c61 *u61; c31 *u31;           /* omega_m^k, k <= h */
   uint64_t r61[9], r61i[9]; uint32_t r31[9], r31i[9];   /* odd root powers */
   uint64_t* x;                  /* [n] the residue: unweighted digits in logical order */
-  uint64_t *pre61; uint32_t* pre31;   /* [n] last squaring before Garner / carry, logical order (input of the GPU carry kernel) */
+  uint64_t *pre61; uint32_t* pre31;   /* [n] last squaring: residues of the unweighted coefficients before Garner / carry, logical order */
+  uint64_t *wtd61; uint32_t* wtd31;   /* [n] the same still weighted (what the fused unweight + Garner + carry kernel of the GPU path reads) */
 } orcc_ctx;
 
 /* m2:479-503 size rule for a forced odd radix: smallest 2^ln with log2(n) + 2 (q/n + 1) < 92 */
@@ -136,6 +137,7 @@ orcc_ctx* orcc_create(uint32_t p, unsigned odd, size_t n_forced) {
   c->width = (uint8_t*)malloc(n); c->w61 = (uint8_t*)malloc(n); c->w31 = (uint8_t*)malloc(n);
   c->j_of = (size_t*)malloc(n * sizeof(size_t));
   c->x = (uint64_t*)calloc(n, 8); c->pre61 = (uint64_t*)calloc(n, 8); c->pre31 = (uint32_t*)calloc(n, 4);
+  c->wtd61 = (uint64_t*)calloc(n, 8); c->wtd31 = (uint32_t*)calloc(n, 4);
   /* widths ceil(p(j+1)/n) - ceil(pj/n) and weight exponents: 2^(1/n) = 2^(n^-1 mod 61) in Z/M61 (2 has order 61), likewise mod 31 */
   const uint64_t l61 = inv_small(n % 61, 61), l31 = inv_small(n % 31, 31);
   uint64_t prev = 0;
@@ -178,7 +180,7 @@ orcc_ctx* orcc_create(uint32_t p, unsigned odd, size_t n_forced) {
 void orcc_destroy(orcc_ctx* c) {
   if (!c) return;
   free(c->width); free(c->w61); free(c->w31); free(c->j_of); free(c->t61); free(c->t61i); free(c->t31); free(c->t31i);
-  free(c->u61); free(c->u31); free(c->x); free(c->pre61); free(c->pre31); free(c);
+  free(c->u61); free(c->u31); free(c->x); free(c->pre61); free(c->pre31); free(c->wtd61); free(c->wtd31); free(c);
 }
 size_t orcc_size(const orcc_ctx* c) { return c->n; }
 void orcc_widths(const orcc_ctx* c, uint8_t* out) { memcpy(out, c->width, c->n); }
@@ -302,8 +304,9 @@ void orcc_square_mul(orcc_ctx* c, uint32_t a) {
     const size_t ra = cb / m, b = cb % m, j = c->j_of[cb];
     const uint64_t v61 = (b & 1) ? z61[ra * h + b / 2].im : z61[ra * h + b / 2].re;
     const uint32_t v31 = (b & 1) ? z31[ra * h + b / 2].im : z31[ra * h + b / 2].re;
-    c->pre61[j] = rot61(m61(v61, s61v), 61 - c->w61[j] % 61);
-    c->pre31[j] = rot31(m31(v31, s31v), 31 - c->w31[j] % 31);
+    c->wtd61[j] = m61(v61, s61v); c->wtd31[j] = m31(v31, s31v);
+    c->pre61[j] = rot61(c->wtd61[j], 61 - c->w61[j] % 61);
+    c->pre31[j] = rot31(c->wtd31[j], 31 - c->w31[j] % 31);
   }
   free(z61); free(z31);
   /* Garner: v = r31 + M31 * ((r61 - r31) / M31 mod M61) < M61 * M31 (m2:429-441); then * a and the carry with wrap-around */
@@ -358,3 +361,5 @@ void orcc_get_words(const orcc_ctx* c, uint32_t* w, size_t count) {
 }
 /* the two residues of every convolution coefficient of the last squaring, before Garner and the carry (logical order) */
 void orcc_get_precarry(const orcc_ctx* c, uint64_t* r61, uint32_t* r31) { memcpy(r61, c->pre61, c->n * 8); memcpy(r31, c->pre31, c->n * 4); }
+/* ... and before the unweighting (scaled by 1 / (odd * h) already) */
+void orcc_get_weighted(const orcc_ctx* c, uint64_t* r61, uint32_t* r31) { memcpy(r61, c->wtd61, c->n * 8); memcpy(r31, c->wtd31, c->n * 4); }

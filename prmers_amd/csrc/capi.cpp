@@ -7,7 +7,11 @@
 #include <string>
 
 #include "engine.hpp"
-namespace mi355 { void selftest_primitives(int device); }
+namespace mi355 {
+void selftest_primitives(int device);
+void crt_carry_host(uint32_t p, size_t n, uint32_t odd, uint32_t a, const uint64_t* in61, const uint32_t* in31, uint64_t* digits_out,
+                    uint64_t* residual_out, int device, double* kernel_ms);
+}
 
 namespace {
 
@@ -120,6 +124,13 @@ int mi355_engine_time_square_mul(mi355_engine_handle h, size_t reg, uint32_t fac
 size_t mi355_engine_kernel_count(mi355_engine_handle) { return mi355::Engine::kKernels; }
 const char* mi355_engine_kernel_name(mi355_engine_handle, size_t k) { return mi355::Engine::kernel_name(k); }
 int mi355_engine_selftest(size_t device) { return guarded([&] { mi355::selftest_primitives(int(device)); }); }
+int mi355_crt_carry(uint32_t exponent, size_t words, uint32_t odd, uint32_t factor, const uint64_t* in61, const uint32_t* in31, uint64_t* digits_out,
+                    uint64_t* residual_out, size_t device, double* kernel_ms) {
+  return guarded([&] {
+    if (!in61 || !in31 || !digits_out || !residual_out) throw std::runtime_error("crt_carry: null buffer");
+    mi355::crt_carry_host(exponent, words, odd, factor, in61, in31, digits_out, residual_out, int(device), kernel_ms);
+  });
+}
 size_t mi355_engine_algorithmic_bytes(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->algorithmic_bytes(); }); return r; }
 
 }  // extern "C"

@@ -74,6 +74,7 @@ def load_library():
         "mi355_engine_mul_add": (C.c_int, [vp, sz, sz, sz, u32]),
         "mi355_engine_square_mul_copy": (C.c_int, [vp, sz, sz, u32]),
         "mi355_engine_mul_copy": (C.c_int, [vp, sz, sz, sz, u32]),
+        "mi355_crt_carry": (C.c_int, [u32, sz, u32, u32, vp, vp, vp, vp, sz, dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -92,7 +93,7 @@ EXPORTS = [
     "mi355_engine_set_data", "mi355_engine_checkpoint_size", "mi355_engine_get_checkpoint",
     "mi355_engine_set_checkpoint", "mi355_engine_time_square_mul", "mi355_engine_kernel_count",
     "mi355_engine_kernel_name", "mi355_engine_algorithmic_bytes", "mi355_engine_selftest",
-    "mi355_engine_addsub", "mi355_engine_addsub_copy", "mi355_engine_mul_add", "mi355_engine_square_mul_copy", "mi355_engine_mul_copy",
+    "mi355_crt_carry", "mi355_engine_addsub", "mi355_engine_addsub_copy", "mi355_engine_mul_add", "mi355_engine_square_mul_copy", "mi355_engine_mul_copy",
 ]
 
 

@@ -29,6 +29,7 @@ def lib():
         L.orcc_set_digits.argtypes = [C.c_void_p, C.c_void_p]
         L.orcc_get_precarry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orcc_get_words.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orcc_get_weighted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -69,6 +70,12 @@ class OracleCrt:
     def precarry(self):
         r61 = np.zeros(self.n, dtype=np.uint64); r31 = np.zeros(self.n, dtype=np.uint32)
         self.L.orcc_get_precarry(self.h, r61.ctypes.data_as(C.c_void_p), r31.ctypes.data_as(C.c_void_p))
+        return r61, r31
+
+    def weighted(self):
+        """residues of the last squaring's coefficients, scaled but still weighted: the input of the GPU carry sweep"""
+        r61 = np.zeros(self.n, dtype=np.uint64); r31 = np.zeros(self.n, dtype=np.uint32)
+        self.L.orcc_get_weighted(self.h, r61.ctypes.data_as(C.c_void_p), r31.ctypes.data_as(C.c_void_p))
         return r61, r31
 
     def words(self):
