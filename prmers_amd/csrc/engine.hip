@@ -110,7 +110,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     v2cols_ = (sel == "v2" || sel == "v2cols") && v2_cols_supported(dp_);
     if (v2rows_ || v2cols_) HIPCHK(v2_configure());
     if (v2cols_) {   // four-step chain starts and ratios: built once on the device (2 x tiles x 512 + 2 x M2 words)
-      const size_t nt = pl_.tiles() * 512;
+      const size_t nt = pl_.tiles() * v2_threads_per_tile(dp_);
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&f0_), (2 * nt + 2 * size_t(pl_.M2)) * 8));
       HIPCHK(v2_build_fourstep(dp_, f0_, f0_ + nt, f0_ + 2 * nt, f0_ + 2 * nt + pl_.M2, stream_));
       HIPCHK(hipStreamSynchronize(stream_));

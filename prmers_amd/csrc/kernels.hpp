@@ -52,6 +52,7 @@ hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hip
 // register-resident radix-8 set (kernels_v2.hip); shapes: rows M2 = 4096, columns M1 = 1024 x C = 4
 bool v2_rows_supported(const DevPlan& pl);
 bool v2_cols_supported(const DevPlan& pl);
+size_t v2_threads_per_tile(const DevPlan& pl);   // 512 (columns of 512 R) or 640 (columns of 1280 = 5 x 256)
 hipError_t v2_configure();
 // fills the chain-start / ratio tables of the column kernels' four-step twiddles (tiles*512, tiles*512, M2, M2 words)
 hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, uint64_t* fbf, uint64_t* fbi, hipStream_t s);

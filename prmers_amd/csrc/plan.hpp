@@ -235,6 +235,23 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
         pl.DI[T * 512 + t] = w;
       }
   }
+  if (pl.r5 == 5 && pl.M1 == 1280 && pl.C == 4 && pl.M2 >= 8) {
+    // columns of 1280 = 5 x 256 (kernels_v2.hip, namespace v5): 640 threads per tile, thread t owns runs i1 = t and t + 640
+    pl.DI.assign(pl.tiles() * 640, 0u);
+    for (size_t T = 0; T < pl.tiles(); ++T)
+      for (uint32_t t = 0; t < 640; ++t) {
+        uint32_t w = 0;
+        for (uint32_t d1 = 0; d1 < 2; ++d1)
+          for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t i1 = 640 * d1 + t, i2 = uint32_t(T) * 4 + (k >> 1);
+            const uint64_t sb = pl.SB[2 * i2 + (k & 1)], s = (uint64_t(pl.SA[i1]) + sb) % n;
+            const uint64_t wa = (k & 1) ? pl.SA[pl.M1 + i1] : pl.SA[i1], wb = pl.SB[2 * i2];
+            const uint32_t wbit = pl.width_of_s(s) - pl.q, wrap = (wa > 0 && wb > 0 && wa + wb <= n) ? 1u : 0u;
+            w |= (wbit | (wrap << 1)) << (2 * (d1 * 8 + k));
+          }
+        pl.DI[T * 640 + t] = w;
+      }
+  }
   if (pl.I4 != (uint64_t(1) << 48)) throw std::runtime_error("internal: omega_4 is expected to be 2^48");   // the kernels shift instead of multiplying
   if (pl.r5 == 5) {
     const uint64_t w5 = gf::pow(om, m / 5);

@@ -32,6 +32,8 @@ SMALL_CASES = [
     # shapes served by the register-resident radix-8 kernels: rows of 4096, columns of 512 x 8, 1024 x 4, 2048 x 2
     (300007, "m2=4096"), (300007, "m2=8,c=4"), (300007, "m2=16,c=8"), (300007, "m2=4,c=2"), (216091, None),
     (600011, "m2=32,c=8"), (600011, "m2=8,c=2"), (1200007, "m2=64,c=8"),
+    # columns of 1280 = 5 x 256 on the register-resident radix-5 kernels (640 threads per tile), generic and radix-8 rows
+    (400063, "m2=8,c=4"), (800283, "m2=16,c=4"), (1600589, "m2=32,c=4"),
     # rows of 8192 (two 4096-point halves under one radix-2 level, 1024 threads)
     (300007, "m2=8192"), (600011, "m2=8192"), (1200007, "m2=8192,c=2"),
 ]
