@@ -3,4 +3,4 @@
 Only what the hot path needs lives here: csrc/ (HIP kernels + C ABI -> libmi355_engine.so) and the
 host-side mirror of the reference's `engine` interface (engine.py) plus its PRP / LL callers (prp.py).
 """
-from .engine import Engine, EngineError, load_library, resolve_plan, LIB_PATH  # noqa: F401
+from .engine import CrtEngine, Engine, EngineError, load_library, resolve_plan, LIB_PATH  # noqa: F401

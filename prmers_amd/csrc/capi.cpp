@@ -6,6 +6,7 @@
 #include <exception>
 #include <string>
 
+#include "crt_engine.hpp"
 #include "engine.hpp"
 namespace mi355 {
 void selftest_primitives(int device);
@@ -28,6 +29,11 @@ int guarded(F&& f) {
     g_last_error = "unknown error";
   }
   return 0;
+}
+
+mi355::CrtEngine* crt(mi355_crt_handle h) {
+  if (!h) throw std::runtime_error("null engine handle");
+  return static_cast<mi355::CrtEngine*>(h);
 }
 
 mi355::Engine* eng(mi355_engine_handle h) {
@@ -131,6 +137,41 @@ int mi355_crt_carry(uint32_t exponent, size_t words, uint32_t odd, uint32_t fact
     mi355::crt_carry_host(exponent, words, odd, factor, in61, in31, digits_out, residual_out, int(device), kernel_ms);
   });
 }
+size_t mi355_crt_transform_size(uint32_t exponent, uint32_t odd) { size_t r = 0; guarded([&] { r = mi355::crt_transform_size(exponent, odd); }); return r; }
+mi355_crt_handle mi355_crt_create(uint32_t exponent, uint32_t odd, size_t words, uint32_t device, const char* spec) {
+  mi355::CrtEngine* e = nullptr;
+  if (!guarded([&] { e = new mi355::CrtEngine(exponent, odd, words, int(device), spec); })) return nullptr;
+  return e;
+}
+void mi355_crt_destroy(mi355_crt_handle h) { guarded([&] { delete static_cast<mi355::CrtEngine*>(h); }); }
+size_t mi355_crt_size(mi355_crt_handle h) { size_t r = 0; guarded([&] { r = crt(h)->size(); }); return r; }
+int mi355_crt_describe(mi355_crt_handle h, char* output, size_t output_size) {
+  return guarded([&] {
+    const std::string s = crt(h)->describe();
+    if (!output || s.size() + 1 > output_size) throw std::runtime_error("describe: output buffer too small");
+    std::memcpy(output, s.c_str(), s.size() + 1);
+  });
+}
+int mi355_crt_sync(mi355_crt_handle h) { return guarded([&] { crt(h)->sync(); }); }
+int mi355_crt_set_u32(mi355_crt_handle h, uint32_t v) { return guarded([&] { crt(h)->set_u32(v); }); }
+int mi355_crt_square_mul(mi355_crt_handle h, uint32_t a) { return guarded([&] { crt(h)->square_mul(a); }); }
+int mi355_crt_sub_u32(mi355_crt_handle h, uint32_t v) { return guarded([&] { crt(h)->sub_u32(v); }); }
+int mi355_crt_get_digits(mi355_crt_handle h, uint64_t* d, size_t count, int canonical) {
+  return guarded([&] { if (!d) throw std::runtime_error("get_digits: null buffer"); crt(h)->get_digits(d, count, canonical != 0); });
+}
+int mi355_crt_set_digits(mi355_crt_handle h, const uint64_t* d, size_t count) {
+  return guarded([&] { if (!d) throw std::runtime_error("set_digits: null buffer"); crt(h)->set_digits(d, count); });
+}
+int mi355_crt_get_words(mi355_crt_handle h, uint32_t* w, size_t count) {
+  return guarded([&] { if (!w) throw std::runtime_error("get_words: null buffer"); crt(h)->get_words(w, count); });
+}
+int mi355_crt_res64(mi355_crt_handle h, uint64_t* out) { return guarded([&] { if (!out) throw std::runtime_error("res64: null output"); *out = crt(h)->res64(); }); }
+int mi355_crt_time_square_mul(mi355_crt_handle h, uint32_t a, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count) {
+  return guarded([&] { crt(h)->time_square_mul(a, iters, total_ms, kernel_ms, kernel_count); });
+}
+size_t mi355_crt_kernel_count(void) { return mi355::CrtEngine::kKernels; }
+const char* mi355_crt_kernel_name(size_t k) { return mi355::CrtEngine::kernel_name(k); }
+size_t mi355_crt_algorithmic_bytes(mi355_crt_handle h) { size_t r = 0; guarded([&] { r = crt(h)->algorithmic_bytes(); }); return r; }
 size_t mi355_engine_algorithmic_bytes(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->algorithmic_bytes(); }); return r; }
 
 }  // extern "C"

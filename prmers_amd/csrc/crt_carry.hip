@@ -12,59 +12,10 @@
 #include <stdexcept>
 #include <string>
 
-#include "gf.hpp"
+#include "crt_field.hpp"
 
 namespace mi355 {
 namespace crt {
-
-constexpr uint64_t M61 = 0x1fffffffffffffffull;
-constexpr uint32_t M31 = 0x7fffffffu;
-constexpr int kRun = 8;
-
-// n = odd << ln; p = q n + t; l61 = n^-1 mod 61, l31 = n^-1 mod 31 (2^(1/n) = 2^l61 in Z/M61); lt61 = l61 t mod 61, lt31 likewise
-struct Geom { uint32_t p, n, odd, ln, l61, l31, q, t, lt61, lt31; uint64_t inv31; uint32_t a; };
-
-__device__ __forceinline__ uint64_t red61(uint64_t x) { x = (x & M61) + (x >> 61); return x >= M61 ? x - M61 : x; }
-__device__ __forceinline__ uint64_t rot61(uint64_t a, uint32_t s) {   // a * 2^s mod M61, a < M61, s < 61
-  if (s == 0) return a;
-  const uint64_t r = ((a << s) & M61) | (a >> (61 - s));
-  return r >= M61 ? r - M61 : r;
-}
-__device__ __forceinline__ uint32_t rot31(uint32_t a, uint32_t s) {
-  if (s == 0) return a;
-  const uint32_t r = ((a << s) & M31) | (a >> (31 - s));
-  return r >= M31 ? r - M31 : r;
-}
-__device__ __forceinline__ uint64_t mul61(uint64_t a, uint64_t b) {
-  uint64_t lo, hi;
-  gf::mul64x64(a, b, lo, hi);                                    // < 2^122
-  return red61((lo & M61) + ((lo >> 61) | (hi << 3)));           // hi 2^64 + lo = (hi 2^3 + lo >> 61) 2^61 + (lo mod 2^61)
-}
-
-// Per digit j the kernels need s_j = p j mod n: the width is q + [s + t > 0] + [s + t > n] - [s > 0] (the difference of two
-// ceilings, plan.hpp width_of_s) and the weight exponent is l (n - s) mod 61 = 1 - l s mod 61 (l n = 1), both kept incrementally:
-// s advances by t, l s by l t, and a wrap of s takes n resp. 1 off -- no division after the run's first digit.
-struct DigitWalk {
-  uint32_t s, A61, A31;   // p j mod n, l61 s mod 61, l31 s mod 31
-  __device__ __forceinline__ void start(const Geom& g, uint32_t j) {
-    s = uint32_t((uint64_t(g.p) * j) % g.n);
-    A61 = uint32_t((uint64_t(g.l61) * (s % 61)) % 61); A31 = uint32_t((uint64_t(g.l31) * (s % 31)) % 31);
-  }
-  __device__ __forceinline__ uint32_t width(const Geom& g) const {
-    const uint64_t st = uint64_t(s) + g.t;
-    return g.q + (st > 0 ? 1u : 0u) + (st > g.n ? 1u : 0u) - (s > 0 ? 1u : 0u);
-  }
-  __device__ __forceinline__ uint32_t unweight61() const { return s ? (A61 + 60) % 61 : 0; }   // 61 - (1 - A) mod 61 = (A - 1) mod 61
-  __device__ __forceinline__ uint32_t unweight31() const { return s ? (A31 + 30) % 31 : 0; }
-  __device__ __forceinline__ void next(const Geom& g) {
-    uint64_t sn = uint64_t(s) + g.t;
-    A61 += g.lt61; A31 += g.lt31;
-    if (sn >= g.n) { sn -= g.n; A61 += 60; A31 += 30; }   // l n = 1 (mod 61 / 31)
-    s = uint32_t(sn);
-    A61 = A61 >= 122 ? A61 - 122 : (A61 >= 61 ? A61 - 61 : A61);
-    A31 = A31 >= 62 ? A31 - 62 : (A31 >= 31 ? A31 - 31 : A31);
-  }
-};
 
 // digits[j]: value mod 2^width_j; carry_out[2 run .. 2 run + 1]: the 128-bit carry leaving the run
 __global__ void __launch_bounds__(256) k_crt_runs(Geom g, const uint64_t* __restrict__ in61, const uint32_t* __restrict__ in31,
@@ -130,30 +81,29 @@ __global__ void __launch_bounds__(256) k_crt_runs_fix(Geom g, uint64_t* __restri
   residual[run] = uint64_t(carry);
 }
 
+// residual[run] (a unit here and there, left by k_crt_runs_fix) goes in front of the following run, without propagation: the digit
+// vector stays weakly carried (a digit may exceed its width by that unit), which the next transform takes as it is
+__global__ void __launch_bounds__(256) k_crt_residual(Geom g, uint64_t* __restrict__ digits, const uint64_t* __restrict__ residual) {
+  const uint32_t run = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t nruns = (g.n + kRun - 1) / kRun;
+  if (run >= nruns) return;
+  const uint64_t c = residual[run ? run - 1 : nruns - 1];
+  if (c) digits[size_t(run) * kRun] += c;
+}
+
 static uint64_t host_pow61(uint64_t a, uint64_t e) {
-  auto mul = [](uint64_t x, uint64_t y) { unsigned __int128 t = (unsigned __int128)x * y; uint64_t lo = uint64_t(t) & M61, hi = uint64_t(t >> 61); uint64_t s = lo + hi; s = (s & M61) + (s >> 61); return s >= M61 ? s - M61 : s; };
   uint64_t r = 1;
-  while (e) { if (e & 1) r = mul(r, a); a = mul(a, a); e >>= 1; }
+  while (e) { if (e & 1) r = mul61(r, a); a = mul61(a, a); e >>= 1; }
   return r;
 }
 
-}  // namespace crt
-
-// host buffers in, host buffers out (a parity / timing entry point, not a resident engine yet); returns the time of the two
-// kernels in ms through *kernel_ms when it is non-null
-void crt_carry_host(uint32_t p, size_t n, uint32_t odd, uint32_t a, const uint64_t* in61, const uint32_t* in31, uint64_t* digits_out,
-                    uint64_t* residual_out, int device, double* kernel_ms) {
-  using namespace crt;
-  if (odd != 1 && odd != 3 && odd != 9) throw std::runtime_error("crt_carry: odd radix must be 1, 3 or 9");
-  if (n == 0 || n % odd || n % kRun || n > 0xfffffff0ull) throw std::runtime_error("crt_carry: bad transform size");
+Geom make_geom(uint32_t p, size_t n, uint32_t odd, uint32_t a) {
+  if (odd != 1 && odd != 3 && odd != 9) throw std::runtime_error("crt: odd radix must be 1, 3 or 9");
+  if (n == 0 || n % odd || n % kRun || n > 0xfffffff0ull) throw std::runtime_error("crt: bad transform size");
   uint32_t ln = 0;
   while ((size_t(odd) << ln) < n) ++ln;
-  if ((size_t(odd) << ln) != n) throw std::runtime_error("crt_carry: transform size must be odd * 2^k");
-  if (a == 0) throw std::runtime_error("crt_carry: factor must be >= 1");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
-  auto chk = [](hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string("crt_carry: ") + what + ": " + hipGetErrorString(e)); };
-  chk(hipSetDevice(device), "hipSetDevice");
+  if ((size_t(odd) << ln) != n) throw std::runtime_error("crt: transform size must be odd * 2^k");
+  if (a == 0) throw std::runtime_error("crt: factor must be >= 1");
   Geom g;
   g.p = p; g.n = uint32_t(n); g.odd = odd; g.ln = ln; g.a = a;
   auto inv_small = [](uint64_t x, uint64_t m) { for (uint64_t y = 1; y < m; ++y) if (x * y % m == 1) return y; return uint64_t(0); };
@@ -161,6 +111,30 @@ void crt_carry_host(uint32_t p, size_t n, uint32_t odd, uint32_t a, const uint64
   g.inv31 = host_pow61(M31, M61 - 2);
   g.q = uint32_t(p / n); g.t = uint32_t(p % n);
   g.lt61 = uint32_t(uint64_t(g.l61) * (g.t % 61) % 61); g.lt31 = uint32_t(uint64_t(g.l31) * (g.t % 31) % 31);
+  return g;
+}
+
+void crt_carry_launch(const Geom& g, const uint64_t* in61, const uint32_t* in31, uint64_t* digits, uint64_t* carry, uint64_t* residual,
+                      bool fold_residual, hipStream_t s) {
+  const size_t nruns = (size_t(g.n) + kRun - 1) / kRun;
+  const dim3 grid(uint32_t((nruns + 255) / 256)), block(256);
+  hipLaunchKernelGGL(k_crt_runs, grid, block, 0, s, g, in61, in31, digits, carry);
+  hipLaunchKernelGGL(k_crt_runs_fix, grid, block, 0, s, g, digits, carry, residual);
+  if (fold_residual) hipLaunchKernelGGL(k_crt_residual, grid, block, 0, s, g, digits, residual);
+}
+
+}  // namespace crt
+
+// host buffers in, host buffers out (a parity / timing entry point of the sweep alone; the resident engine is crt_engine.hip);
+// returns the time of the two kernels in ms through *kernel_ms when it is non-null
+void crt_carry_host(uint32_t p, size_t n, uint32_t odd, uint32_t a, const uint64_t* in61, const uint32_t* in31, uint64_t* digits_out,
+                    uint64_t* residual_out, int device, double* kernel_ms) {
+  using namespace crt;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
+  auto chk = [](hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string("crt_carry: ") + what + ": " + hipGetErrorString(e)); };
+  const Geom g = make_geom(p, n, odd, a);
+  chk(hipSetDevice(device), "hipSetDevice");
   const size_t nruns = (n + kRun - 1) / kRun;
   uint64_t *d61 = nullptr, *dd = nullptr, *dc = nullptr, *dr = nullptr; uint32_t* d31 = nullptr;
   chk(hipMalloc(reinterpret_cast<void**>(&d61), n * 8), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&d31), n * 4), "hipMalloc");
@@ -169,11 +143,9 @@ void crt_carry_host(uint32_t p, size_t n, uint32_t odd, uint32_t a, const uint64
   chk(hipMemcpy(d61, in61, n * 8, hipMemcpyHostToDevice), "copy"); chk(hipMemcpy(d31, in31, n * 4, hipMemcpyHostToDevice), "copy");
   hipEvent_t e0, e1;
   chk(hipEventCreate(&e0), "event"); chk(hipEventCreate(&e1), "event");
-  const dim3 grid(uint32_t((nruns + 255) / 256)), block(256);
   for (int rep = 0; rep < (kernel_ms ? 5 : 1); ++rep) {   // timed runs repeat the sweep (same inputs, same outputs)
     chk(hipEventRecord(e0), "event");
-    hipLaunchKernelGGL(crt::k_crt_runs, grid, block, 0, 0, g, d61, d31, dd, dc);
-    hipLaunchKernelGGL(crt::k_crt_runs_fix, grid, block, 0, 0, g, dd, dc, dr);
+    crt_carry_launch(g, d61, d31, dd, dc, dr, false, nullptr);
     chk(hipEventRecord(e1), "event");
     chk(hipEventSynchronize(e1), "sync");
   }

@@ -1,0 +1,539 @@
+// Squaring x <- x^2 a mod 2^p - 1 over GF(M61^2) x GF(M31^2) with a prime-factor (Good-Thomas) axis of radix 1, 3 or 9:
+// the second field family of the reference.  Reference: the Aevum backend, third_party/aevum/src/cl/
+// fft-middle.cl:663-720 (pfaDft3, radix 9 = 3 x 3 with scalar roots), pfaunpack.cl:12-56 (index map), carry.cl:506-588, policy
+// README.md:907-926; CPU illustration docs/mersenne2_mixed_crt_2d_half_fast/mersenne2_mixed_crt_2d_half_fast.cpp ("m2:").
+//
+// n = odd * m words of up to 39 bits, m = 2^ln.  Logical digit j sits at grid coordinate (a, b) = (j mod odd, j mod m); there are no
+// twiddles between the two axes (m2:733-758).  Row a of the grid is a real sequence of length m, held as h = m / 2 values of
+// Z/p[i] (slot s = (b = 2s) + i (b = 2s + 1)), once for p = M61 (16 bytes a slot) and once for p = M31 (8 bytes): 12 bytes a word.
+//   front      digits -> weight (bit rotations) -> DFT of length odd along a with scalar roots -> Z[a][s]
+//   rows       half-length complex DFT of every row, h = H1 x H2 four-step (columns of H1 through LDS, twiddle omega_h^(k1 i2),
+//              rows of H2 through LDS); frequency k = k1 + H1 k2 ends at slot k1 H2 + k2
+//   pointwise  conjugate-symmetric untangling of the packed real rows, square, re-tangle (m2:829-915 in its textbook split form)
+//   rows^-1, back: inverse odd DFT, 1 / (odd h), scatter to logical order; then the fused unweight + Garner + carry sweep of
+//              crt_carry.hip.
+// This file is the straightforward kernel set (radix-2 butterflies in LDS, one launch per stage): parity first, see DESIGN.md for
+// the measured cost and what the register-resident version has to beat.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "crt_engine.hpp"
+#include "crt_field.hpp"
+
+namespace mi355 {
+namespace crt {
+
+constexpr uint32_t kPassElems = 2048;   // complex values of one work-group of a row pass (32 KiB of LDS for M61)
+
+struct Grid {
+  uint32_t odd, ln, m, h, logh, logH1, logH2, minv;   // h = 2^logh = H1 H2; minv = m^-1 mod odd
+  uint64_t r61[9], r61i[9], s61;                      // odd-root powers, their inverses, 1 / (odd h)
+  uint32_t r31[9], r31i[9], s31;
+};
+
+template <class F>
+__device__ __forceinline__ typename F::C tw_m(const typename F::C* __restrict__ U, uint32_t e, uint32_t h) {   // omega_m^e, e < m = 2h
+  return e < h ? U[e] : cneg<F>(U[e - h]);
+}
+
+__device__ __forceinline__ uint32_t brev(uint32_t i, uint32_t bits) { return bits ? (__brev(i) >> (32 - bits)) : 0u; }
+
+// ---- front: weight + odd axis --------------------------------------------------------------------------------------------
+// thread = slot s of every row: the 2 odd digits b + m t (b = 2s, 2s + 1; t < odd) are exactly the grid column pair, digit
+// b + m t at row a = (b + m t) mod odd.  Weight exponents come from the digit's own p j mod n (DigitWalk::start).
+template <int ODD>
+__global__ void __launch_bounds__(256) k_front(Geom g, Grid gr, const uint64_t* __restrict__ x, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= gr.h) return;
+  F61::C in61[ODD]; F31::C in31[ODD];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const uint32_t b = 2 * s + half;
+#pragma unroll
+    for (int a = 0; a < ODD; ++a) {
+      const uint32_t t = ODD > 1 ? ((uint32_t(a) + ODD - b % ODD) % ODD) * gr.minv % ODD : 0u;
+      const uint32_t j = b + gr.m * t;
+      const uint64_t v = x[j];
+      DigitWalk dw; dw.start(g, j);
+      const uint64_t v61 = rot61(red61(v), dw.weight61());
+      const uint32_t v31 = rot31(red31(v), dw.weight31());
+      if (half == 0) { in61[a].re = v61; in31[a].re = v31; } else { in61[a].im = v61; in31[a].im = v31; }
+    }
+  }
+#pragma unroll
+  for (int ka = 0; ka < ODD; ++ka) {
+    F61::C o61 = in61[0]; F31::C o31 = in31[0];
+#pragma unroll
+    for (int a = 1; a < ODD; ++a) {
+      const int e = (a * ka) % ODD;
+      o61 = cadd<F61>(o61, e ? cscale<F61>(in61[a], gr.r61[e]) : in61[a]);
+      o31 = cadd<F31>(o31, e ? cscale<F31>(in31[a], gr.r31[e]) : in31[a]);
+    }
+    Z61[size_t(ka) * gr.h + s] = o61; Z31[size_t(ka) * gr.h + s] = o31;
+  }
+}
+
+// ---- back: inverse odd axis, 1 / (odd h), scatter to logical order -------------------------------------------------------
+template <int ODD>
+__global__ void __launch_bounds__(256) k_back(Grid gr, const F61::C* __restrict__ Z61, const F31::C* __restrict__ Z31, uint64_t* __restrict__ out61,
+                                              uint32_t* __restrict__ out31) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= gr.h) return;
+  F61::C in61[ODD]; F31::C in31[ODD];
+#pragma unroll
+  for (int a = 0; a < ODD; ++a) { in61[a] = Z61[size_t(a) * gr.h + s]; in31[a] = Z31[size_t(a) * gr.h + s]; }
+#pragma unroll
+  for (int a = 0; a < ODD; ++a) {
+    F61::C o61 = in61[0]; F31::C o31 = in31[0];
+#pragma unroll
+    for (int ka = 1; ka < ODD; ++ka) {
+      const int e = (a * ka) % ODD;
+      o61 = cadd<F61>(o61, e ? cscale<F61>(in61[ka], gr.r61i[e]) : in61[ka]);
+      o31 = cadd<F31>(o31, e ? cscale<F31>(in31[ka], gr.r31i[e]) : in31[ka]);
+    }
+    o61 = cscale<F61>(o61, gr.s61); o31 = cscale<F31>(o31, gr.s31);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t b = 2 * s + half;
+      const uint32_t t = ODD > 1 ? ((uint32_t(a) + ODD - b % ODD) % ODD) * gr.minv % ODD : 0u;
+      const uint32_t j = b + gr.m * t;
+      out61[j] = half ? o61.im : o61.re; out31[j] = half ? o31.im : o31.re;
+    }
+  }
+}
+
+// ---- one pass of the row transforms --------------------------------------------------------------------------------------
+// A work-group holds CA transforms of length L = 2^logL in LDS.  cols != 0: the transforms are the columns i2 .. i2 + CA - 1 of
+// the H1 x H2 view of one row (stride H2), followed (forward) or preceded (inverse) by the four-step twiddle omega_h^(+-k1 i2);
+// cols == 0: they are CA consecutive contiguous segments (the rows of that view, or whole grid rows when H1 = 1).
+// Radix-2 decimation in frequency; the bit-reversed result is read back in natural order.
+template <class F>
+__global__ void __launch_bounds__(256) k_pass(Grid gr, typename F::C* __restrict__ Z, const typename F::C* __restrict__ U, uint32_t logL, uint32_t CA,
+                                              int cols, int inverse) {
+  using C = typename F::C;
+  __shared__ C X[kPassElems];
+  const uint32_t L = 1u << logL, tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t per_row = gr.h >> logL;               // transforms per grid row
+  const uint32_t d0 = blockIdx.x * CA;                 // first transform of this group (CA divides per_row)
+  const uint32_t row = d0 / per_row, r0 = d0 - row * per_row;
+  C* base = Z + size_t(row) * gr.h;
+  const uint32_t H2 = 1u << gr.logH2;
+  // load
+  for (uint32_t e = tid; e < CA * L; e += nt) {
+    uint32_t c, i; size_t addr;
+    if (cols) { c = e % CA; i = e / CA; addr = size_t(i) * H2 + (r0 + c); }
+    else { i = e & (L - 1); c = e >> logL; addr = size_t(r0 + c) * L + i; }
+    C v = base[addr];
+    if (cols && inverse) {   // conj(omega_h^(k1 i2)) = conj(omega_m^(2 k1 i2)): here i is k1
+      v = cmul<F>(v, cconj<F>(tw_m<F>(U, 2u * i * (r0 + c), gr.h)));
+    }
+    X[c * L + i] = v;
+  }
+  // butterflies
+  const uint32_t ushift = gr.ln - logL;                // omega_L^j = omega_m^(j m / L)
+  for (uint32_t half = L >> 1, sh = 0; half >= 1; half >>= 1, ++sh) {
+    __syncthreads();
+    for (uint32_t bfy = tid; bfy < CA * (L >> 1); bfy += nt) {
+      const uint32_t c = bfy / (L >> 1), q = bfy - c * (L >> 1);
+      const uint32_t j = q & (half - 1), i = ((q - j) << 1) + j;
+      const C u = X[c * L + i], v = X[c * L + i + half];
+      C w = U[size_t(j << sh) << ushift];
+      if (inverse) w = cconj<F>(w);
+      X[c * L + i] = cadd<F>(u, v);
+      X[c * L + i + half] = (j == 0) ? csub<F>(u, v) : cmul<F>(csub<F>(u, v), w);
+    }
+  }
+  __syncthreads();
+  // store, natural order
+  for (uint32_t e = tid; e < CA * L; e += nt) {
+    uint32_t c, k; size_t addr;
+    if (cols) { c = e % CA; k = e / CA; addr = size_t(k) * H2 + (r0 + c); }
+    else { k = e & (L - 1); c = e >> logL; addr = size_t(r0 + c) * L + k; }
+    C v = X[c * L + brev(k, logL)];
+    if (cols && !inverse) v = cmul<F>(v, tw_m<F>(U, 2u * k * (r0 + c), gr.h));
+    base[addr] = v;
+  }
+}
+
+// ---- pointwise -----------------------------------------------------------------------------------------------------------
+// Row of m reals packed as h complex values z; Z = DFT_h(z).  With W = omega_m:
+//   X_k = (Z_k + conj Z_{-k}) / 2 + W^k (Z_k - conj Z_{-k}) / (2i)          k = 0 .. h      (the real sequence's spectrum)
+//   Y_k = X_k^2
+//   Z'_k = (Y_k + conj Y_{h-k}) / 2 + i conj(W^k) (Y_k - conj Y_{h-k}) / 2  k = 0 .. h - 1  (packed spectrum of the square)
+// One thread owns the pair (k, h - k), k <= h / 2; frequency k = k1 + H1 k2 sits at slot k1 H2 + k2.
+__device__ __forceinline__ uint32_t slot_of(const Grid& gr, uint32_t k) { return ((k & ((1u << gr.logH1) - 1)) << gr.logH2) + (k >> gr.logH1); }
+
+template <class F>
+__device__ __forceinline__ typename F::C spectrum_sq(typename F::C zk, typename F::C zmk, typename F::C w) {
+  const typename F::C zc = cconj<F>(zmk);
+  const typename F::C e = cadd<F>(zk, zc), o = cdiv_i<F>(csub<F>(zk, zc));
+  return csqr<F>(chalf<F>(cadd<F>(e, cmul<F>(w, o))));
+}
+template <class F>
+__device__ __forceinline__ typename F::C repack(typename F::C yk, typename F::C yhk, typename F::C w) {
+  const typename F::C yc = cconj<F>(yhk);
+  const typename F::C e = cadd<F>(yk, yc), d = cmul<F>(csub<F>(yk, yc), cconj<F>(w));
+  return chalf<F>(cadd<F>(e, cmul_i<F>(d)));
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_pointwise(Grid gr, typename F::C* __restrict__ Z, const typename F::C* __restrict__ U) {
+  using C = typename F::C;
+  const uint32_t per_row = (gr.h >> 1) + 1;
+  const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= per_row * gr.odd) return;
+  const uint32_t row = idx / per_row, k = idx - row * per_row;
+  C* z = Z + size_t(row) * gr.h;
+  const uint32_t h = gr.h;
+  if (k == 0) {
+    const C z0 = z[0];
+    const C y0 = spectrum_sq<F>(z0, z0, U[0]);            // X_0
+    const C yh = spectrum_sq<F>(z0, z0, U[h]);            // X_h (W^h = -1)
+    z[0] = repack<F>(y0, yh, U[0]);
+    if (h >= 2) {   // the self-paired middle slot
+      const uint32_t sm = slot_of(gr, h >> 1);
+      const C zm = z[sm];
+      const C ym = spectrum_sq<F>(zm, zm, U[h >> 1]);
+      z[sm] = repack<F>(ym, ym, U[h >> 1]);
+    }
+    return;
+  }
+  if (2 * k >= h) return;   // k = h / 2 was handled with k = 0
+  const uint32_t sa = slot_of(gr, k), sb = slot_of(gr, h - k);
+  const C za = z[sa], zb = z[sb];
+  const C wa = U[k], wb = U[h - k];
+  const C ya = spectrum_sq<F>(za, zb, wa), yb = spectrum_sq<F>(zb, za, wb);
+  z[sa] = repack<F>(ya, yb, wa);
+  z[sb] = repack<F>(yb, ya, wb);
+}
+
+// ---- small helpers -------------------------------------------------------------------------------------------------------
+__global__ void k_set_small(Geom g, uint64_t* __restrict__ x, uint32_t a) {   // x = a (one thread: a touches at most a few digits)
+  if (blockIdx.x || threadIdx.x) return;
+  uint64_t v = a;
+  DigitWalk dw; dw.start(g, 0);
+  for (uint32_t j = 0; j < g.n && v; ++j) { const uint32_t w = dw.width(g); x[j] = v & ((uint64_t(1) << w) - 1); v >>= w; dw.next(g); }
+}
+__global__ void k_sub_small(Geom g, uint64_t* __restrict__ x, uint32_t a) {   // x -= a with borrow and wrap-around (m2:1095-1111)
+  if (blockIdx.x || threadIdx.x) return;
+  uint64_t borrow = a;
+  for (int lap = 0; lap < 3 && borrow; ++lap) {
+    DigitWalk dw; dw.start(g, 0);
+    for (uint32_t j = 0; j < g.n && borrow; ++j) {
+      const uint32_t w = dw.width(g);
+      const uint64_t v = x[j];
+      if (v >= borrow) { x[j] = v - borrow; borrow = 0; }
+      else { const uint64_t need = borrow - v, k = (need + (uint64_t(1) << w) - 1) >> w; x[j] = v + (k << w) - borrow; borrow = k; }
+      dw.next(g);
+    }
+  }
+}
+
+}  // namespace crt
+
+// ==========================================================================================================================
+// host
+// ==========================================================================================================================
+namespace {
+
+using crt::F31; using crt::F61; using crt::M31; using crt::M61;
+
+void chk(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string("crt engine: ") + what + ": " + hipGetErrorString(e)); }
+
+uint64_t pow61(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = crt::mul61(r, a); a = crt::mul61(a, a); e >>= 1; } return r; }
+uint32_t pow31(uint32_t a, uint64_t e) { uint32_t r = 1; while (e) { if (e & 1) r = crt::mul31(r, a); a = crt::mul31(a, a); e >>= 1; } return r; }
+
+// an element of exact order 2^k in the norm-1 subgroup of Z/p[i] (order p + 1 = 2^61 resp. 2^31): (t + i)^((p - 1) 2^(bits - k)) for the first t
+// that gives exact order 2^k; the exponent is applied as (p - 1) first (z^(p-1) = conj(z) / z has norm 1), then by squaring
+template <class F>
+typename F::C root_2k(unsigned k, unsigned bits) {
+  using C = typename F::C;
+  for (typename F::S t = 2;; ++t) {
+    const C g{t, 1};
+    // g^(p-1): p - 1 = 2^bits - 2
+    C r{1, 0}, b = g;
+    for (unsigned i = 0; i < bits; ++i) { if (i >= 1) r = crt::cmul<F>(r, b); b = crt::cmul<F>(b, b); }   // sum of 2^i, i = 1 .. bits-1 = 2^bits - 2
+    for (unsigned i = k; i < bits; ++i) r = crt::cmul<F>(r, r);                                          // ^ 2^(bits - k)
+    C z = r;
+    for (unsigned i = 1; i < k; ++i) z = crt::cmul<F>(z, z);
+    if (z.re == F::M - 1 && z.im == 0) return r;   // r^(2^(k-1)) = -1: exact order 2^k
+  }
+}
+
+template <class S, class POW>
+S odd_root(unsigned odd, S modulus, POW pw) {   // a primitive odd-th root of unity among the scalars (odd | p - 1)
+  for (S g = 2;; ++g) {
+    const S r = pw(g, (uint64_t(modulus) - 1) / odd);
+    bool ok = r != 1;
+    for (unsigned d = 2; ok && d < odd; ++d) if (odd % d == 0 && pw(r, odd / d) == 1) ok = false;
+    if (ok && pw(r, odd) == 1) return r;
+  }
+}
+
+}  // namespace
+
+size_t crt_transform_size(uint32_t p, uint32_t odd) {   // m2:479-503: smallest odd 2^ln with log2(n) + 2 (p / n + 1) < 92
+  for (unsigned ln = 3; ln <= 28; ++ln) {
+    const size_t n = size_t(odd) << ln;
+    if (n > p) break;
+    if (std::log2(double(n)) + 2.0 * (double(p) / double(n) + 1.0) < 92.0) return n;
+  }
+  return 0;
+}
+
+struct CrtEngine::Impl {
+  crt::Geom g;
+  crt::Grid gr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t* x = nullptr;          // [n] digits, logical order, weakly carried
+  F61::C *Z61 = nullptr, *U61 = nullptr;
+  F31::C *Z31 = nullptr, *U31 = nullptr;
+  uint64_t *w61 = nullptr, *carry = nullptr, *residual = nullptr;
+  uint32_t* w31 = nullptr;
+  hipEvent_t ev[kKernels + 1] = {};
+  std::vector<uint8_t> width;
+};
+
+const char* CrtEngine::kernel_name(size_t k) {
+  static const char* names[kKernels] = {"k_front", "k_rows_fwd", "k_pointwise", "k_rows_inv", "k_back", "k_crt_carry"};
+  return k < kKernels ? names[k] : "";
+}
+
+CrtEngine::CrtEngine(uint32_t p, uint32_t odd, size_t n_forced, int device, const char* spec) : im_(new Impl) {
+  Impl& im = *im_;
+  try {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
+    if (odd != 1 && odd != 3 && odd != 9) throw std::runtime_error("crt engine: odd radix must be 1, 3 or 9");
+    const size_t n = n_forced ? n_forced : crt_transform_size(p, odd);
+    if (!n) throw std::runtime_error("crt engine: no admissible transform size for this exponent");
+    if (std::log2(double(n)) + 2.0 * (double(p) / double(n) + 1.0) >= 92.0) throw std::runtime_error("crt engine: transform too small for this exponent");
+    im.g = crt::make_geom(p, n, odd, 1);
+    crt::Grid& gr = im.gr;
+    gr.odd = odd; gr.ln = im.g.ln; gr.m = 1u << gr.ln; gr.h = gr.m >> 1; gr.logh = gr.ln - 1;
+    if (gr.ln < 3) throw std::runtime_error("crt engine: power-of-two axis too short");
+    uint32_t logH2 = std::min<uint32_t>(10, gr.logh);
+    if (spec && std::strncmp(spec, "h2=", 3) == 0) logH2 = uint32_t(std::atoi(spec + 3));
+    if (logH2 < 1 || logH2 > std::min<uint32_t>(10, gr.logh) || gr.logh - logH2 > 10) throw std::runtime_error("crt engine: bad row split");
+    gr.logH2 = logH2; gr.logH1 = gr.logh - logH2;
+    gr.minv = 0;
+    if (odd > 1) for (uint32_t y = 1; y < odd; ++y) if ((uint64_t(gr.m % odd) * y) % odd == 1) gr.minv = y;
+    const uint64_t r61 = odd > 1 ? odd_root<uint64_t>(odd, M61, pow61) : 1;
+    const uint32_t r31 = odd > 1 ? odd_root<uint32_t>(odd, M31, pow31) : 1;
+    for (unsigned k = 0; k < 9; ++k) {
+      gr.r61[k] = pow61(r61, k % odd); gr.r61i[k] = pow61(r61, (odd - k % odd) % odd);
+      gr.r31[k] = pow31(r31, k % odd); gr.r31i[k] = pow31(r31, (odd - k % odd) % odd);
+    }
+    gr.s61 = pow61((uint64_t(odd) * gr.h) % M61, M61 - 2); gr.s31 = pow31(uint32_t((uint64_t(odd) * gr.h) % M31), M31 - 2);
+
+    im.device = device;
+    chk(hipSetDevice(device), "hipSetDevice");
+    chk(hipStreamCreateWithFlags(&im.stream, hipStreamNonBlocking), "stream");
+    for (auto& e : im.ev) chk(hipEventCreate(&e), "event");
+    const size_t h = gr.h, nruns = (n + crt::kRun - 1) / crt::kRun;
+    chk(hipMalloc(reinterpret_cast<void**>(&im.x), n * 8), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&im.Z61), size_t(odd) * h * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.Z31), size_t(odd) * h * 8), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&im.U61), (h + 1) * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.U31), (h + 1) * 8), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&im.w61), n * 8), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.w31), n * 4), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&im.carry), nruns * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.residual), nruns * 8), "hipMalloc");
+    chk(hipMemset(im.x, 0, n * 8), "memset");
+    // omega_m^k, k <= h
+    {
+      std::vector<F61::C> u61(h + 1); std::vector<F31::C> u31(h + 1);
+      const F61::C w61 = root_2k<F61>(gr.ln, 61); const F31::C w31 = root_2k<F31>(gr.ln, 31);
+      F61::C a{1, 0}; F31::C b{1, 0};
+      for (size_t k = 0; k <= h; ++k) { u61[k] = a; u31[k] = b; a = crt::cmul<F61>(a, w61); b = crt::cmul<F31>(b, w31); }
+      chk(hipMemcpy(im.U61, u61.data(), (h + 1) * 16, hipMemcpyHostToDevice), "copy"); chk(hipMemcpy(im.U31, u31.data(), (h + 1) * 8, hipMemcpyHostToDevice), "copy");
+    }
+    im.width.resize(n);
+    uint64_t prev = 0;
+    for (size_t j = 0; j < n; ++j) { const uint64_t next = (uint64_t(p) * (j + 1) + n - 1) / n; im.width[j] = uint8_t(next - prev); prev = next; }
+  } catch (...) {
+    release();
+    throw;
+  }
+}
+
+void CrtEngine::release() {
+  if (!im_) return;
+  Impl& im = *im_;
+  (void)hipSetDevice(im.device);
+  if (im.stream) (void)hipStreamSynchronize(im.stream);
+  for (void* q : {static_cast<void*>(im.x), static_cast<void*>(im.Z61), static_cast<void*>(im.Z31), static_cast<void*>(im.U61), static_cast<void*>(im.U31),
+                  static_cast<void*>(im.w61), static_cast<void*>(im.w31), static_cast<void*>(im.carry), static_cast<void*>(im.residual)})
+    if (q) (void)hipFree(q);
+  for (auto& e : im.ev) if (e) (void)hipEventDestroy(e);
+  if (im.stream) (void)hipStreamDestroy(im.stream);
+  delete im_;
+  im_ = nullptr;
+}
+CrtEngine::~CrtEngine() { release(); }
+
+size_t CrtEngine::size() const { return im_->g.n; }
+uint32_t CrtEngine::odd() const { return im_->g.odd; }
+uint32_t CrtEngine::exponent() const { return im_->g.p; }
+std::string CrtEngine::describe() const {
+  const crt::Grid& gr = im_->gr;
+  return "crt-hip:n=" + std::to_string(im_->g.n) + ":odd=" + std::to_string(gr.odd) + ":m=" + std::to_string(gr.m) + ":h1=" + std::to_string(1u << gr.logH1) + ":h2=" +
+         std::to_string(1u << gr.logH2);
+}
+size_t CrtEngine::algorithmic_bytes() const { return size_t(im_->g.n) * (8 + 8 + 2 * 12 + 8 * 12); }   // digits r + w, carry sweep input, 4 row passes r + w
+
+void CrtEngine::sync() {
+  chk(hipSetDevice(im_->device), "hipSetDevice");
+  chk(hipStreamSynchronize(im_->stream), "sync");
+  chk(hipGetLastError(), "kernel");
+}
+
+template <class F>
+static void launch_rows(const crt::Grid& gr, typename F::C* Z, const typename F::C* U, bool inverse, hipStream_t s) {
+  auto pass = [&](uint32_t logL, int cols) {
+    const uint32_t L = 1u << logL;
+    uint32_t CA = std::max<uint32_t>(1, crt::kPassElems / L);
+    const uint32_t per_row = gr.h >> logL;
+    CA = std::min(CA, per_row);                       // powers of two: CA divides per_row
+    const uint32_t groups = gr.odd * per_row / CA;
+    hipLaunchKernelGGL((crt::k_pass<F>), dim3(groups), dim3(256), 0, s, gr, Z, U, logL, CA, cols, inverse ? 1 : 0);
+  };
+  if (!inverse) {
+    if (gr.logH1) pass(gr.logH1, 1);
+    pass(gr.logH2, 0);
+  } else {
+    pass(gr.logH2, 0);
+    if (gr.logH1) pass(gr.logH1, 1);
+  }
+}
+
+void CrtEngine::launch_square(uint32_t a, bool timed) {
+  Impl& im = *im_;
+  const crt::Grid& gr = im.gr;
+  crt::Geom g = im.g; g.a = a;
+  hipStream_t s = im.stream;
+  const dim3 b256(256), gslots((gr.h + 255) / 256);
+  int e = 0;
+  auto mark = [&] { if (timed) chk(hipEventRecord(im.ev[e++], s), "event"); };
+  mark();
+  switch (gr.odd) {
+    case 1: hipLaunchKernelGGL((crt::k_front<1>), gslots, b256, 0, s, g, gr, im.x, im.Z61, im.Z31); break;
+    case 3: hipLaunchKernelGGL((crt::k_front<3>), gslots, b256, 0, s, g, gr, im.x, im.Z61, im.Z31); break;
+    default: hipLaunchKernelGGL((crt::k_front<9>), gslots, b256, 0, s, g, gr, im.x, im.Z61, im.Z31); break;
+  }
+  mark();
+  launch_rows<F61>(gr, im.Z61, im.U61, false, s);
+  launch_rows<F31>(gr, im.Z31, im.U31, false, s);
+  mark();
+  const uint32_t pw = ((gr.h >> 1) + 1) * gr.odd;
+  hipLaunchKernelGGL((crt::k_pointwise<F61>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z61, im.U61);
+  hipLaunchKernelGGL((crt::k_pointwise<F31>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z31, im.U31);
+  mark();
+  launch_rows<F61>(gr, im.Z61, im.U61, true, s);
+  launch_rows<F31>(gr, im.Z31, im.U31, true, s);
+  mark();
+  switch (gr.odd) {
+    case 1: hipLaunchKernelGGL((crt::k_back<1>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;
+    case 3: hipLaunchKernelGGL((crt::k_back<3>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;
+    default: hipLaunchKernelGGL((crt::k_back<9>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;
+  }
+  mark();
+  crt::crt_carry_launch(g, im.w61, im.w31, im.x, im.carry, im.residual, true, s);
+  mark();
+}
+
+void CrtEngine::square_mul(uint32_t a) {
+  if (a == 0) throw std::runtime_error("square_mul: factor must be >= 1");
+  chk(hipSetDevice(im_->device), "hipSetDevice");
+  launch_square(a, false);
+}
+
+void CrtEngine::set_u32(uint32_t a) {
+  Impl& im = *im_;
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  chk(hipMemsetAsync(im.x, 0, size_t(im.g.n) * 8, im.stream), "memset");
+  if (a) hipLaunchKernelGGL(crt::k_set_small, dim3(1), dim3(1), 0, im.stream, im.g, im.x, a);
+}
+void CrtEngine::sub_u32(uint32_t a) {
+  Impl& im = *im_;
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  if (a) hipLaunchKernelGGL(crt::k_sub_small, dim3(1), dim3(1), 0, im.stream, im.g, im.x, a);
+}
+
+void CrtEngine::set_digits(const uint64_t* d, size_t count) {
+  Impl& im = *im_;
+  if (count != im.g.n) throw std::runtime_error("set_digits: wrong digit count");
+  for (size_t j = 0; j < count; ++j) if (d[j] >> 62) throw std::runtime_error("set_digits: digit out of range");
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  chk(hipStreamSynchronize(im.stream), "sync");
+  chk(hipMemcpy(im.x, d, count * 8, hipMemcpyHostToDevice), "copy");
+}
+
+// digits as they are on the device (weakly carried) or canonical: strong carry with wrap-around, 2^p - 1 stays all ones
+void CrtEngine::get_digits(uint64_t* d, size_t count, bool canonical) {
+  Impl& im = *im_;
+  if (count != im.g.n) throw std::runtime_error("get_digits: wrong digit count");
+  sync();
+  chk(hipMemcpy(d, im.x, count * 8, hipMemcpyDeviceToHost), "copy");
+  if (!canonical) return;
+  uint64_t carry = 0;
+  for (int lap = 0; lap < 4; ++lap) {
+    for (size_t j = 0; j < count; ++j) {
+      const uint64_t v = d[j] + carry;
+      d[j] = v & ((uint64_t(1) << im.width[j]) - 1);
+      carry = v >> im.width[j];
+      if (lap && !carry) break;
+    }
+    if (!carry) break;
+  }
+}
+
+// canonical little-endian 32-bit words of the residue, 2^p - 1 -> 0 (what the plugin ABI exchanges: EngineApi.cpp:210-218)
+void CrtEngine::get_words(uint32_t* w, size_t count) {
+  Impl& im = *im_;
+  const size_t n = im.g.n, need = (size_t(im.g.p) + 31) / 32;
+  if (count < need) throw std::runtime_error("get_words: buffer too small");
+  std::vector<uint64_t> d(n);
+  get_digits(d.data(), n, true);
+  bool ones = true;
+  for (size_t j = 0; j < n && ones; ++j) ones = d[j] == ((uint64_t(1) << im.width[j]) - 1);
+  std::memset(w, 0, count * 4);
+  if (ones) return;
+  size_t bit = 0;
+  for (size_t j = 0; j < n; ++j) {
+    const size_t wi = bit >> 5, sh = bit & 31;
+    const unsigned __int128 v = (unsigned __int128)d[j] << sh;
+    w[wi] |= uint32_t(v);
+    if (wi + 1 < count) w[wi + 1] |= uint32_t(v >> 32);
+    if (wi + 2 < count) w[wi + 2] |= uint32_t(v >> 64);
+    bit += im.width[j];
+  }
+}
+uint64_t CrtEngine::res64() {
+  std::vector<uint32_t> w((size_t(im_->g.p) + 31) / 32 + 2, 0);
+  get_words(w.data(), w.size());
+  return uint64_t(w[0]) | (uint64_t(w[1]) << 32);
+}
+
+void CrtEngine::time_square_mul(uint32_t a, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count) {
+  Impl& im = *im_;
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  std::vector<double> acc(kKernels, 0.0);
+  double total = 0;
+  for (size_t it = 0; it < iters; ++it) {
+    launch_square(a, true);
+    chk(hipEventSynchronize(im.ev[kKernels]), "sync");
+    for (int k = 0; k < kKernels; ++k) { float ms = 0; chk(hipEventElapsedTime(&ms, im.ev[k], im.ev[k + 1]), "elapsed"); acc[k] += ms; }
+    float ms = 0; chk(hipEventElapsedTime(&ms, im.ev[0], im.ev[kKernels]), "elapsed"); total += ms;
+  }
+  chk(hipGetLastError(), "kernel");
+  if (total_ms) *total_ms = iters ? total / double(iters) : 0;
+  for (size_t k = 0; k < kernel_count && k < size_t(kKernels); ++k) if (kernel_ms) kernel_ms[k] = iters ? acc[k] / double(iters) : 0;
+}
+
+}  // namespace mi355

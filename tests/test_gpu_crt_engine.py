@@ -1,0 +1,102 @@
+"""The resident GF(M61^2) x GF(M31^2) squaring engine with a prime-factor radix-3 / radix-9 axis (prmers_amd/csrc/crt_engine.hip,
+SURVEY.md 8f N1; reference third_party/aevum/src/cl/fft-middle.cl:663-720, pfaunpack.cl:12-56, carry.cl:506-588) through the C ABI,
+against the CRT oracle (oracle/oracle_crt.c), Python integers and the libgmp pins.  Needs a real MI355X:  python -m pytest tests -m gpu"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc_crt
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def CrtEngine(*a, **k):
+    from prmers_amd import CrtEngine as E
+    return E(*a, **k)
+
+
+# (exponent, odd radix, forced words or 0, plan): single-pass rows, two-pass rows (h2 forces the four-step split at small sizes)
+CASES = [(521, 1, 0, None), (607, 3, 0, None), (1279, 9, 0, None), (9941, 9, 0, None), (9941, 3, 0, "h2=2"), (11213, 9, 9 << 6, "h2=3"),
+         (44497, 1, 0, "h2=4"), (86243, 9, 0, "h2=5"), (216091, 3, 0, None), (216091, 9, 9 << 11, "h2=6"), (1257787, 9, 0, None),
+         (3021377, 1, 0, None), (3021377, 3, 3 << 17, "h2=7")]
+
+
+@pytest.mark.parametrize("p,odd,n,plan", CASES)
+def test_square_mul_matches_the_oracle_digit_for_digit(p, odd, n, plan):
+    with CrtEngine(p, odd, n, plan=plan) as e:
+        o = orc_crt.OracleCrt(p, odd, e.n)   # the engine's automatic size is the reference's rule with at least 8 words per odd residue class
+        assert e.n == o.n and (n == 0 or e.n == n)
+        rng = np.random.default_rng(p + odd)
+        w = o.widths().astype(np.uint64)
+        start = rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))
+        o.set_digits(start); e.set_digits(start)
+        for it, a in enumerate((1, 3, 1, 1)):
+            o.square_mul(a); e.square_mul(a)
+            assert np.array_equal(e.digits(), o.digits()), (p, odd, plan, it)
+        assert np.array_equal(e.words(), o.words())
+        assert e.res64() == o.value() & ((1 << 64) - 1)
+
+
+@pytest.mark.parametrize("p,odd", [(127, 1), (521, 3), (1279, 9), (2203, 9), (2281, 3)])
+def test_lucas_lehmer_verdicts(p, odd):
+    """complete LL tests of small Mersenne primes and of composites next to them, every iterate against Python integers"""
+    for q, prime in ((p, True), (p + 2, False)):
+        try:
+            e = CrtEngine(q, odd)
+        except Exception:
+            if q == p:
+                raise
+            continue
+        with e:
+            Mq = (1 << q) - 1
+            s = 4
+            e.set(4)
+            for i in range(q - 2):
+                e.square_mul(1); e.sub(2)
+                s = (s * s - 2) % Mq
+                if i % 97 == 0 or i == q - 3:
+                    assert e.get_int() == s, (q, i)
+            assert (e.get_int() == 0) == prime
+
+
+def test_set_sub_and_all_ones():
+    p, odd = 9941, 9
+    with CrtEngine(p, odd) as e:
+        Mp = (1 << p) - 1
+        e.set(5); assert e.get_int() == 5
+        e.sub(7); assert e.get_int() == Mp - 2            # borrow through every digit and around
+        e.square_mul(1); assert e.get_int() == 4
+        o = orc_crt.OracleCrt(p, odd)
+        ones = (np.uint64(1) << o.widths().astype(np.uint64)) - np.uint64(1)
+        e.set_digits(ones)
+        assert e.get_int() == 0 and e.res64() == 0        # 2^p - 1 reads as zero
+        e.square_mul(3); assert e.get_int() == 0
+
+
+@pytest.mark.parametrize("odd,n", [(9, 9 << 20), (3, 3 << 21)])
+def test_pfa_sizes_of_config_4_against_the_gmp_pins_and_the_oracle(odd, n):
+    """p = 205271257 at the forced radix-9 size 9 * 2^20 and the automatic radix-3 size 3 * 2^21 (BASELINE configs[3], README.md:907-926):
+    3^(2^k) against the libgmp pins, and one seeded squaring against the oracle"""
+    p = 205271257
+    import hashlib
+    pins = {c["iteration"]: c for c in json.load(open(os.path.join(HERE, "golden", "big_p_pins.json")))["pins"][str(p)]}
+    with CrtEngine(p, odd, n) as e:
+        assert e.n == n
+        e.set(3)
+        for k in range(1, max(pins) + 1):
+            e.square_mul(1)
+            if k in pins:
+                assert e.res64() == int(pins[k]["res64"], 16), k
+                assert hashlib.sha256(e.words().astype("<u4").tobytes()).hexdigest() == pins[k]["sha256_words"], k
+        o = orc_crt.OracleCrt(p, odd, n)
+        rng = np.random.default_rng(1)
+        w = o.widths().astype(np.uint64)
+        start = rng.integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))
+        o.set_digits(start); e.set_digits(start)
+        o.square_mul(3); e.square_mul(3)
+        assert np.array_equal(e.digits(), o.digits())
+        total, per = e.time_square_mul(20)
+        print("crt engine p=%d %s: %.4f ms/iter %s" % (p, e.describe(), total, {k: round(v, 4) for k, v in per.items()}))
