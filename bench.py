@@ -59,6 +59,50 @@ def cpu_baseline(p, sample_iters=100):
             "sample": "%d squarings at p=%d (n=%d) by oracle/oracle.c, OpenMP" % (sample_iters, p, o.n)}
 
 
+def bench_crt(args):
+    """BASELINE configs[3] taken literally: p = 205271257 at the radix-9 size 9 * 2^20 (or --odd 3: 3 * 2^21) on the second field
+    family.  Same timing discipline as the headline line (preheat, warm-up, K steps between synchronisations), one GPU."""
+    import numpy as np
+    import torch
+    from prmers_amd import CrtEngine
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--field crt is a single-GPU line")
+    p = args.exponent or 205271257
+    eng = CrtEngine(p, args.odd, args.words)
+    n = eng.n
+    j = np.arange(n + 1, dtype=np.uint64)
+    ceil = (j * np.uint64(p) + np.uint64(n - 1)) // np.uint64(n)
+    width = (ceil[1:] - ceil[:-1]).astype(np.uint64)
+    eng.set_digits(np.random.default_rng(1000).integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << width) - np.uint64(1)))
+    t_start = time.perf_counter()
+    while args.preheat_seconds > 0 and time.perf_counter() - t_start < args.preheat_seconds:
+        for _ in range(50):
+            eng.square_mul(1)
+        eng.sync()
+    for _ in range(max(1, args.warmup)):
+        eng.square_mul(1)
+    eng.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.square_mul(1)
+    eng.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _, kern = eng.time_square_mul(min(args.steps, 32))
+    ms = 1e3 * elapsed / args.steps
+    dom = max(kern, key=kern.get)
+    bytes_iter = eng.algorithmic_bytes()
+    out = {"metric": "squaring throughput at p=%d over GF(M61^2) x GF(M31^2), PFA radix-%d axis" % (p, args.odd), "value": round(args.steps / elapsed, 3),
+           "unit": "iter/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u64 + u32 (GF(M61^2) x GF(M31^2))", "data": "synthetic",
+           "config": {"workload": "square_mul x<-x^2 mod 2^p-1, p=%d, n=%d words (odd radix %d)" % (p, n, args.odd), "plan": eng.describe()},
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(bytes_iter / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(bytes_iter / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_iteration": bytes_iter, "stage_ms": {k: round(v, 5) for k, v in kern.items()},
+                        "note": "whole iteration (stages are several launches each); first kernel set, see DESIGN.md section N1"}}
+    print(json.dumps(out))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +111,10 @@ def main():
     ap.add_argument("--exponent", type=int, default=0, help="override the exponent (testing)")
     ap.add_argument("--plan", type=str, default=None, help="plan override, e.g. m2=4096,c=4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--field", default="goldilocks", choices=["goldilocks", "crt"],
+                    help="crt: the GF(M61^2) x GF(M31^2) engine with the prime-factor radix-3/9 axis (SURVEY.md 8f N1; one GPU, not the headline line)")
+    ap.add_argument("--odd", type=int, default=9, help="--field crt: radix of the odd axis (1, 3, 9)")
+    ap.add_argument("--words", type=int, default=0, help="--field crt: transform words (0: smallest admissible)")
     ap.add_argument("--preheat-seconds", type=float, default=2.0,
                     help="untimed clock ramp before the warm-up: at least this long and until two batches agree within 1 %% (0: off)")
     ap.add_argument("--allow-gloo", action="store_true",
@@ -79,6 +127,8 @@ def main():
     import torch
     from prmers_amd import Engine
 
+    if args.field == "crt":
+        return bench_crt(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

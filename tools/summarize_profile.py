@@ -41,6 +41,10 @@ def main(d):
     res["traffic"] = traffic
     sq = avg_counter(os.path.join(d, "pmc_sq", "*", "*counter_collection.csv"))
     res["sq"] = {k: v for k, v in sq.items() if "mi355" in k}
+    sq2 = avg_counter(os.path.join(d, "pmc_sq2", "*", "*counter_collection.csv"))
+    for k, v in sq2.items():
+        if "mi355" in k:
+            res["sq"].setdefault(k, {}).update(v)
     for name in ("bench_trace.log",):
         p = os.path.join(d, name)
         if os.path.exists(p):
