@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -214,6 +215,12 @@ __global__ void __launch_bounds__(256) k_pointwise(Grid gr, typename F::C* __res
   z[sb] = repack<F>(yb, ya, wb);
 }
 
+}  // namespace crt
+}  // namespace mi355
+#include "crt_rows.hpp"
+namespace mi355 {
+namespace crt {
+
 // ---- small helpers -------------------------------------------------------------------------------------------------------
 __global__ void k_set_small(Geom g, uint64_t* __restrict__ x, uint32_t a) {   // x = a (one thread: a touches at most a few digits)
   if (blockIdx.x || threadIdx.x) return;
@@ -267,6 +274,25 @@ typename F::C root_2k(unsigned k, unsigned bits) {
   }
 }
 
+// r^t for the odd t < 8 that makes r^(2^(ln-3)) the wanted 8th root (the four primitive 8th roots are the odd powers of any one)
+template <class F>
+typename F::C normalise_root(typename F::C r, unsigned ln, typename F::C want) {
+  using C = typename F::C;
+  C w8 = r;
+  for (unsigned i = 3; i < ln; ++i) w8 = crt::cmul<F>(w8, w8);
+  C p = w8;
+  const C w8sq = crt::cmul<F>(w8, w8);
+  for (unsigned t = 1; t < 8; t += 2) {
+    if (p.re == want.re && p.im == want.im) {
+      C out{1, 0};
+      for (unsigned i = 0; i < t; ++i) out = crt::cmul<F>(out, r);
+      return out;
+    }
+    p = crt::cmul<F>(p, w8sq);
+  }
+  throw std::runtime_error("crt engine: no 8th root of the expected form");
+}
+
 template <class S, class POW>
 S odd_root(unsigned odd, S modulus, POW pw) {   // a primitive odd-th root of unity among the scalars (odd | p - 1)
   for (S g = 2;; ++g) {
@@ -298,6 +324,9 @@ struct CrtEngine::Impl {
   F31::C *Z31 = nullptr, *U31 = nullptr;
   uint64_t *w61 = nullptr, *carry = nullptr, *residual = nullptr;
   uint32_t* w31 = nullptr;
+  bool fast = false;              // crt_rows.hpp kernels (rows of 1024, columns of 2 .. 2048)
+  F61::C *W1_61 = nullptr, *W2_61 = nullptr, *V61 = nullptr;
+  F31::C *W1_31 = nullptr, *W2_31 = nullptr, *V31 = nullptr;
   hipEvent_t ev[kKernels + 1] = {};
   std::vector<uint8_t> width;
 };
@@ -317,6 +346,9 @@ CrtEngine::CrtEngine(uint32_t p, uint32_t odd, size_t n_forced, int device, cons
     if (!n) throw std::runtime_error("crt engine: no admissible transform size for this exponent");
     if (std::log2(double(n)) + 2.0 * (double(p) / double(n) + 1.0) >= 92.0) throw std::runtime_error("crt engine: transform too small for this exponent");
     im.g = crt::make_geom(p, n, odd, 1);
+    // the carry sweep hands a run's carry to the next run and lets it die inside that run's kRun digits: (kRun - 1) words must hold a
+    // coefficient of up to 92 bits (every size the reference's rule picks has more than 20 bits per word)
+    if (uint64_t(im.g.q) * (crt::kRun - 1) < 100) throw std::runtime_error("crt engine: fewer than 15 bits per word at this transform size");
     crt::Grid& gr = im.gr;
     gr.odd = odd; gr.ln = im.g.ln; gr.m = 1u << gr.ln; gr.h = gr.m >> 1; gr.logh = gr.ln - 1;
     if (gr.ln < 3) throw std::runtime_error("crt engine: power-of-two axis too short");
@@ -348,10 +380,31 @@ CrtEngine::CrtEngine(uint32_t p, uint32_t odd, size_t n_forced, int device, cons
     // omega_m^k, k <= h
     {
       std::vector<F61::C> u61(h + 1); std::vector<F31::C> u31(h + 1);
-      const F61::C w61 = root_2k<F61>(gr.ln, 61); const F31::C w31 = root_2k<F31>(gr.ln, 31);
+      // the generator is rotated (an odd power keeps its order) so that omega_m^(m/8) is (1 + i) / sqrt 2 = (1 + i) 2^30 resp. (1 + i) 2^15:
+      // the radix-8 steps of crt_rows.hpp multiply by that root with an add, a sub and two bit rotations
+      const F61::C w61 = normalise_root<F61>(root_2k<F61>(gr.ln, 61), gr.ln, F61::C{uint64_t(1) << 30, uint64_t(1) << 30});
+      const F31::C w31 = normalise_root<F31>(root_2k<F31>(gr.ln, 31), gr.ln, F31::C{1u << 15, 1u << 15});
       F61::C a{1, 0}; F31::C b{1, 0};
       for (size_t k = 0; k <= h; ++k) { u61[k] = a; u31[k] = b; a = crt::cmul<F61>(a, w61); b = crt::cmul<F31>(b, w31); }
       chk(hipMemcpy(im.U61, u61.data(), (h + 1) * 16, hipMemcpyHostToDevice), "copy"); chk(hipMemcpy(im.U31, u31.data(), (h + 1) * 8, hipMemcpyHostToDevice), "copy");
+      const char* ks = std::getenv("MI355_CRT_KERNELS");
+      im.fast = gr.logH2 == 10 && gr.logH1 >= 1 && gr.logH1 <= 11 && !(ks && std::strcmp(ks, "generic") == 0);
+      if (im.fast) {
+        // omega_L^x = omega_m^(x m / L) for the two pass lengths (x < L; beyond h through omega_m^h = -1), omega_m^(H1 k2)
+        auto pick61 = [&](size_t e) { return e <= h ? u61[e] : crt::cneg<F61>(u61[e - h]); };
+        auto pick31 = [&](size_t e) { return e <= h ? u31[e] : crt::cneg<F31>(u31[e - h]); };
+        const size_t H1 = size_t(1) << gr.logH1, H2 = size_t(1) << gr.logH2, m = size_t(gr.m);
+        std::vector<F61::C> t61; std::vector<F31::C> t31;
+        auto upload = [&](size_t count, size_t stride, F61::C*& d61, F31::C*& d31) {
+          t61.resize(count); t31.resize(count);
+          for (size_t x = 0; x < count; ++x) { t61[x] = pick61(x * stride); t31[x] = pick31(x * stride); }
+          chk(hipMalloc(reinterpret_cast<void**>(&d61), count * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&d31), count * 8), "hipMalloc");
+          chk(hipMemcpy(d61, t61.data(), count * 16, hipMemcpyHostToDevice), "copy"); chk(hipMemcpy(d31, t31.data(), count * 8, hipMemcpyHostToDevice), "copy");
+        };
+        upload(H1, m / H1, im.W1_61, im.W1_31);
+        upload(H2, m / H2, im.W2_61, im.W2_31);
+        upload(H2, H1, im.V61, im.V31);
+      }
     }
     im.width.resize(n);
     uint64_t prev = 0;
@@ -368,7 +421,9 @@ void CrtEngine::release() {
   (void)hipSetDevice(im.device);
   if (im.stream) (void)hipStreamSynchronize(im.stream);
   for (void* q : {static_cast<void*>(im.x), static_cast<void*>(im.Z61), static_cast<void*>(im.Z31), static_cast<void*>(im.U61), static_cast<void*>(im.U31),
-                  static_cast<void*>(im.w61), static_cast<void*>(im.w31), static_cast<void*>(im.carry), static_cast<void*>(im.residual)})
+                  static_cast<void*>(im.w61), static_cast<void*>(im.w31), static_cast<void*>(im.carry), static_cast<void*>(im.residual),
+                  static_cast<void*>(im.W1_61), static_cast<void*>(im.W2_61), static_cast<void*>(im.V61), static_cast<void*>(im.W1_31),
+                  static_cast<void*>(im.W2_31), static_cast<void*>(im.V31)})
     if (q) (void)hipFree(q);
   for (auto& e : im.ev) if (e) (void)hipEventDestroy(e);
   if (im.stream) (void)hipStreamDestroy(im.stream);
@@ -383,7 +438,7 @@ uint32_t CrtEngine::exponent() const { return im_->g.p; }
 std::string CrtEngine::describe() const {
   const crt::Grid& gr = im_->gr;
   return "crt-hip:n=" + std::to_string(im_->g.n) + ":odd=" + std::to_string(gr.odd) + ":m=" + std::to_string(gr.m) + ":h1=" + std::to_string(1u << gr.logH1) + ":h2=" +
-         std::to_string(1u << gr.logH2);
+         std::to_string(1u << gr.logH2) + (im_->fast ? ":radix8" : ":generic");
 }
 size_t CrtEngine::algorithmic_bytes() const { return size_t(im_->g.n) * (8 + 8 + 2 * 12 + 8 * 12); }   // digits r + w, carry sweep input, 4 row passes r + w
 
@@ -427,16 +482,27 @@ void CrtEngine::launch_square(uint32_t a, bool timed) {
     default: hipLaunchKernelGGL((crt::k_front<9>), gslots, b256, 0, s, g, gr, im.x, im.Z61, im.Z31); break;
   }
   mark();
-  launch_rows<F61>(gr, im.Z61, im.U61, false, s);
-  launch_rows<F31>(gr, im.Z31, im.U31, false, s);
-  mark();
-  const uint32_t pw = ((gr.h >> 1) + 1) * gr.odd;
-  hipLaunchKernelGGL((crt::k_pointwise<F61>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z61, im.U61);
-  hipLaunchKernelGGL((crt::k_pointwise<F31>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z31, im.U31);
-  mark();
-  launch_rows<F61>(gr, im.Z61, im.U61, true, s);
-  launch_rows<F31>(gr, im.Z31, im.U31, true, s);
-  mark();
+  if (im.fast) {
+    const crt::FastTables T{im.W1_61, im.W2_61, im.V61, im.U61, im.W1_31, im.W2_31, im.V31, im.U31};
+    const uint32_t CA = crt::kFastSlots >> gr.logH1, gcols = gr.odd * ((1u << gr.logH2) / CA), gmid = gr.odd * (1u << gr.logH1) / 2;
+    hipLaunchKernelGGL((crt::k_cols_fast<false>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    mark();
+    hipLaunchKernelGGL(crt::k_mid_fast, dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    mark();
+    hipLaunchKernelGGL((crt::k_cols_fast<true>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    mark();   // slots: k_rows_fwd = forward columns, k_pointwise = the fused row kernel, k_rows_inv = inverse columns
+  } else {
+    launch_rows<F61>(gr, im.Z61, im.U61, false, s);
+    launch_rows<F31>(gr, im.Z31, im.U31, false, s);
+    mark();
+    const uint32_t pw = ((gr.h >> 1) + 1) * gr.odd;
+    hipLaunchKernelGGL((crt::k_pointwise<F61>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z61, im.U61);
+    hipLaunchKernelGGL((crt::k_pointwise<F31>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z31, im.U31);
+    mark();
+    launch_rows<F61>(gr, im.Z61, im.U61, true, s);
+    launch_rows<F31>(gr, im.Z31, im.U31, true, s);
+    mark();
+  }
   switch (gr.odd) {
     case 1: hipLaunchKernelGGL((crt::k_back<1>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;
     case 3: hipLaunchKernelGGL((crt::k_back<3>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;

@@ -1,0 +1,255 @@
+// Row transforms of the GF(M61^2) x GF(M31^2) squaring, second kernel set: 256 threads hold 2048 complex slots of BOTH fields
+// (8 per thread) in three 8-byte LDS planes (re61, im61, (re31, im31)) and run a mixed-radix 8.8.8.{1,2,4} decimation-in-frequency
+// in place -- 4 LDS round trips for 1024 points instead of 10, general twiddles on 7/8 of the slots once per radix-8 step instead
+// of on half of them every level, and the 8th roots inside a step are (1 +- i) 2^30 resp. (1 +- i) 2^15: an add, a sub and two bit
+// rotations (the host rotates its generator so that omega_m^(m/8) is exactly that root).
+//   k_cols_fast   columns of the H1 x H2 view of a row (CA = 2048 / H1 adjacent columns per work-group) + four-step twiddle
+//   k_mid_fast    rows k1 and H1 - k1 (H2 = 1024 slots each): forward, conjugate-symmetric untangle + square + re-tangle against the
+//                 partner row in LDS, inverse -- one launch and one pass over the data for what were five launches
+// Frequencies are left in the digit-reversed order of the in-place transform inside a kernel and in natural order in HBM.
+// Reference for the algebra: third_party/aevum/src/cl/fft-middle.cl, fftp.cl (the tail square), docs/mersenne2_mixed_crt_2d_half_fast/
+// mersenne2_mixed_crt_2d_half_fast.cpp:829-915.  Included by crt_engine.hip only.
+#pragma once
+
+namespace mi355 {
+namespace crt {
+
+constexpr uint32_t kFastSlots = 2048;
+constexpr uint32_t kFastPlane = kFastSlots + kFastSlots / 16;   // skewed by a + a / 16
+constexpr uint32_t kFastLdsBytes = kFastPlane * 8 * 3;
+
+struct FastTables {   // per field: omega_L^x for the two pass lengths (x < L), omega_m^(H1 k2) (k2 < H2), omega_m^k (k <= h)
+  const F61::C *w1_61, *w2_61, *v61, *u61;
+  const F31::C *w1_31, *w2_31, *v31, *u31;
+};
+
+struct Planes { uint64_t* re; uint64_t* im; uint2* c3; };
+
+__device__ __forceinline__ uint32_t skw(uint32_t a) { return a + (a >> 4); }
+
+template <class F> struct Slot;
+template <> struct Slot<F61> {
+  static __device__ __forceinline__ F61::C get(const Planes& P, uint32_t a) { const uint32_t s = skw(a); return {P.re[s], P.im[s]}; }
+  static __device__ __forceinline__ void put(const Planes& P, uint32_t a, F61::C v) { const uint32_t s = skw(a); P.re[s] = v.re; P.im[s] = v.im; }
+};
+template <> struct Slot<F31> {
+  static __device__ __forceinline__ F31::C get(const Planes& P, uint32_t a) { const uint2 v = P.c3[skw(a)]; return {v.x, v.y}; }
+  static __device__ __forceinline__ void put(const Planes& P, uint32_t a, F31::C v) { P.c3[skw(a)] = make_uint2(v.re, v.im); }
+};
+
+// multiplication by the 8th root (1 + i) / sqrt 2 and by its conjugate: 1 / sqrt 2 = 2^30 in Z/M61, 2^15 in Z/M31
+template <class F> struct Rot8;
+template <> struct Rot8<F61> { static __device__ __forceinline__ uint64_t r(uint64_t a) { return rot61(a, 30); } };
+template <> struct Rot8<F31> { static __device__ __forceinline__ uint32_t r(uint32_t a) { return rot31(a, 15); } };
+template <class F, bool INV>
+__device__ __forceinline__ typename F::C mul_w8(typename F::C a) {
+  if (!INV) return {Rot8<F>::r(F::sub(a.re, a.im)), Rot8<F>::r(F::add(a.re, a.im))};
+  return {Rot8<F>::r(F::add(a.re, a.im)), Rot8<F>::r(F::sub(a.im, a.re))};
+}
+template <class F, bool INV>
+__device__ __forceinline__ typename F::C mul_w4(typename F::C a) { return INV ? cdiv_i<F>(a) : cmul_i<F>(a); }   // omega_4 = i
+
+// out[k] = sum_q in[q] w^(qk), w = omega_R (forward) or its conjugate (INV, unnormalised); natural order in and out
+template <class F, int R, bool INV>
+__device__ __forceinline__ void bfly(typename F::C (&x)[R]) {
+  using C = typename F::C;
+  if (R == 2) {
+    const C a = cadd<F>(x[0], x[1]), b = csub<F>(x[0], x[1]);
+    x[0] = a; x[1] = b;
+  } else if (R == 4) {
+    const C a0 = cadd<F>(x[0], x[2]), a1 = cadd<F>(x[1], x[3]), b0 = csub<F>(x[0], x[2]), b1 = mul_w4<F, INV>(csub<F>(x[1], x[3]));
+    x[0] = cadd<F>(a0, a1); x[2] = csub<F>(a0, a1); x[1] = cadd<F>(b0, b1); x[3] = csub<F>(b0, b1);
+  } else {
+    const C a0 = cadd<F>(x[0], x[4]), a1 = cadd<F>(x[1], x[5]), a2 = cadd<F>(x[2], x[6]), a3 = cadd<F>(x[3], x[7]);
+    const C b0 = csub<F>(x[0], x[4]), b1 = mul_w8<F, INV>(csub<F>(x[1], x[5])), b2 = mul_w4<F, INV>(csub<F>(x[2], x[6])),
+            b3 = mul_w4<F, INV>(mul_w8<F, INV>(csub<F>(x[3], x[7])));
+    const C c0 = cadd<F>(a0, a2), c1 = cadd<F>(a1, a3), d0 = csub<F>(a0, a2), d1 = mul_w4<F, INV>(csub<F>(a1, a3));
+    const C e0 = cadd<F>(b0, b2), e1 = cadd<F>(b1, b3), f0 = csub<F>(b0, b2), f1 = mul_w4<F, INV>(csub<F>(b1, b3));
+    x[0] = cadd<F>(c0, c1); x[4] = csub<F>(c0, c1); x[2] = cadd<F>(d0, d1); x[6] = csub<F>(d0, d1);
+    x[1] = cadd<F>(e0, e1); x[5] = csub<F>(e0, e1); x[3] = cadd<F>(f0, f1); x[7] = csub<F>(f0, f1);
+  }
+}
+
+// one in-place step of radix R = 2^LR on sub-transforms of size 2^logS inside transforms of size 2^logL (2048 slots per work-group):
+// forward: butterfly, then y_k *= omega_S^(jk); inverse: x_k *= conj(omega_S^(jk)), then the conjugate butterfly.  WL[x] = omega_L^x.
+template <class F, int LR, bool INV>
+__device__ __forceinline__ void step(const Planes& P, uint32_t tid, uint32_t logL, uint32_t logS, const typename F::C* __restrict__ WL) {
+  using C = typename F::C;
+  constexpr int R = 1 << LR, G = 8 / R;
+  const uint32_t logSr = logS - LR;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const uint32_t bf = tid * G + g;
+    const uint32_t c = bf >> (logL - LR), bfl = bf & ((1u << (logL - LR)) - 1);
+    const uint32_t j = bfl & ((1u << logSr) - 1), blk = bfl >> logSr;
+    const uint32_t base = (c << logL) + (blk << logS) + j;
+    C x[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) x[q] = Slot<F>::get(P, base + (uint32_t(q) << logSr));
+    if (INV && logSr) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) x[k] = cmul<F>(x[k], cconj<F>(WL[(j * uint32_t(k)) << (logL - logS)]));
+    }
+    bfly<F, R, INV>(x);
+    if (!INV && logSr) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) x[k] = cmul<F>(x[k], WL[(j * uint32_t(k)) << (logL - logS)]);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) Slot<F>::put(P, base + (uint32_t(q) << logSr), x[q]);
+  }
+}
+
+// radices of a transform of length 2^logL: radix 8 while three bits are left, then the rest
+__device__ __forceinline__ uint32_t step_bits(uint32_t logS) { return logS >= 3 ? 3u : logS; }
+
+template <bool INV>
+__device__ __forceinline__ void transform_both(const Planes& P, uint32_t tid, uint32_t logL, const F61::C* __restrict__ W61, const F31::C* __restrict__ W31) {
+  // forward: sizes logL, logL - 3, ...; inverse: the same steps in reverse order
+  uint32_t sizes[4]; int ns = 0;
+  for (uint32_t logS = logL; logS; logS -= step_bits(logS)) sizes[ns++] = logS;
+  for (int t = 0; t < ns; ++t) {
+    const uint32_t logS = sizes[INV ? ns - 1 - t : t];
+    const uint32_t lr = step_bits(logS);
+    __syncthreads();
+    if (lr == 3) { step<F61, 3, INV>(P, tid, logL, logS, W61); step<F31, 3, INV>(P, tid, logL, logS, W31); }
+    else if (lr == 2) { step<F61, 2, INV>(P, tid, logL, logS, W61); step<F31, 2, INV>(P, tid, logL, logS, W31); }
+    else { step<F61, 1, INV>(P, tid, logL, logS, W61); step<F31, 1, INV>(P, tid, logL, logS, W31); }
+  }
+  __syncthreads();
+}
+
+// position of frequency k after the in-place forward transform (mixed-radix digit reversal), and its inverse
+__device__ __forceinline__ uint32_t pos_of_freq(uint32_t k, uint32_t logL) {
+  uint32_t p = 0;
+  for (uint32_t logS = logL; logS;) { const uint32_t lr = step_bits(logS); logS -= lr; p += (k & ((1u << lr) - 1)) << logS; k >>= lr; }
+  return p;
+}
+__device__ __forceinline__ uint32_t freq_of_pos(uint32_t p, uint32_t logL) {
+  uint32_t k = 0, sh = 0;
+  for (uint32_t logS = logL; logS;) { const uint32_t lr = step_bits(logS); logS -= lr; k += ((p >> logS) & ((1u << lr) - 1)) << sh; sh += lr; }
+  return k;
+}
+
+__device__ __forceinline__ Planes planes_of(unsigned char* smem) {
+  Planes P;
+  P.re = reinterpret_cast<uint64_t*>(smem); P.im = P.re + kFastPlane; P.c3 = reinterpret_cast<uint2*>(P.im + kFastPlane);
+  return P;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem_crt[];
+
+// ---- columns ----
+template <bool INV>
+__global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
+  const Planes P = planes_of(smem_crt);
+  const uint32_t tid = threadIdx.x, logL = gr.logH1, L = 1u << logL, H2 = 1u << gr.logH2;
+  const uint32_t CA = kFastSlots >> logL, per_row = H2 / CA;
+  const uint32_t row = blockIdx.x / per_row, col0 = (blockIdx.x - row * per_row) * CA;
+  F61::C* z61 = Z61 + size_t(row) * gr.h; F31::C* z31 = Z31 + size_t(row) * gr.h;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t e = tid + 256u * it, c = e % CA, i = e / CA;        // i: row index i1 (forward) or frequency k1 (inverse)
+    const size_t addr = size_t(i) * H2 + col0 + c;
+    F61::C a = z61[addr]; F31::C b = z31[addr];
+    uint32_t slot = (c << logL) + i;
+    if (INV) {
+      const uint32_t tw = 2u * i * (col0 + c);                          // conj(omega_h^(k1 i2))
+      a = cmul<F61>(a, cconj<F61>(tw < gr.h ? T.u61[tw] : cneg<F61>(T.u61[tw - gr.h])));
+      b = cmul<F31>(b, cconj<F31>(tw < gr.h ? T.u31[tw] : cneg<F31>(T.u31[tw - gr.h])));
+      slot = (c << logL) + pos_of_freq(i, logL);
+    }
+    Slot<F61>::put(P, slot, a); Slot<F31>::put(P, slot, b);
+  }
+  transform_both<INV>(P, tid, logL, T.w1_61, T.w1_31);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t e = tid + 256u * it, c = e % CA, i = e / CA;        // i: frequency k1 (forward) or row index i1 (inverse)
+    const uint32_t slot = (c << logL) + (INV ? i : pos_of_freq(i, logL));
+    F61::C a = Slot<F61>::get(P, slot); F31::C b = Slot<F31>::get(P, slot);
+    if (!INV) {
+      const uint32_t tw = 2u * i * (col0 + c);
+      a = cmul<F61>(a, tw < gr.h ? T.u61[tw] : cneg<F61>(T.u61[tw - gr.h]));
+      b = cmul<F31>(b, tw < gr.h ? T.u31[tw] : cneg<F31>(T.u31[tw - gr.h]));
+    }
+    const size_t addr = size_t(i) * H2 + col0 + c;
+    z61[addr] = a; z31[addr] = b;
+  }
+}
+
+// ---- middle: rows k1 and H1 - k1 (work-group 0 of a grid row: rows 0 and H1 / 2, each its own partner) ----
+template <class F>
+__device__ __forceinline__ void pointwise_pair(const Planes& P, uint32_t sa, uint32_t sb, typename F::C wa) {
+  using C = typename F::C;
+  const C za = Slot<F>::get(P, sa), zb = Slot<F>::get(P, sb);
+  const C wb = cneg<F>(cconj<F>(wa));                                   // omega_m^(h - k) = -conj(omega_m^k)
+  const C ya = spectrum_sq<F>(za, zb, wa), yb = spectrum_sq<F>(zb, za, wb);
+  Slot<F>::put(P, sa, repack<F>(ya, yb, wa));
+  Slot<F>::put(P, sb, repack<F>(yb, ya, wb));
+}
+template <class F>
+__device__ __forceinline__ void pointwise_self(const Planes& P, uint32_t s, typename F::C w) {   // k = h / 2: its own partner
+  const typename F::C z = Slot<F>::get(P, s);
+  const typename F::C y = spectrum_sq<F>(z, z, w);
+  Slot<F>::put(P, s, repack<F>(y, y, w));
+}
+template <class F>
+__device__ __forceinline__ void pointwise_zero(const Planes& P, uint32_t s) {                      // k = 0 with k = h folded in
+  using C = typename F::C;
+  const C z = Slot<F>::get(P, s);
+  const C one{1, 0}, mone{F::M - 1, 0};
+  const C y0 = spectrum_sq<F>(z, z, one), yh = spectrum_sq<F>(z, z, mone);
+  Slot<F>::put(P, s, repack<F>(y0, yh, one));
+}
+
+__global__ void __launch_bounds__(256) k_mid_fast(Grid gr, FastTables T, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
+  const Planes P = planes_of(smem_crt);
+  const uint32_t tid = threadIdx.x, logL = gr.logH2, L = 1u << logL, H1 = 1u << gr.logH1;   // L = 1024: two rows per work-group
+  const uint32_t per_row = H1 >> 1;
+  const uint32_t row = blockIdx.x / per_row, b = blockIdx.x - row * per_row;
+  const uint32_t k1a = b, k1b = b ? H1 - b : (H1 >> 1);
+  F61::C* z61 = Z61 + size_t(row) * gr.h; F31::C* z31 = Z31 + size_t(row) * gr.h;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t e = tid + 256u * it, r = e >> logL, i = e & (L - 1);
+    const size_t addr = size_t(r ? k1b : k1a) * L + i;
+    Slot<F61>::put(P, e, z61[addr]); Slot<F31>::put(P, e, z31[addr]);
+  }
+  transform_both<false>(P, tid, logL, T.w2_61, T.w2_31);
+  // pointwise: 1024 pairs (4 per thread)
+  const F61::C ua61 = T.u61[k1a], ub61 = T.u61[k1b]; const F31::C ua31 = T.u31[k1a], ub31 = T.u31[k1b];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const uint32_t q = tid + 256u * it;                                 // 0 .. 1023
+    if (b) {                                                            // (row a, k2 = q) <-> (row b, k2 = L - 1 - q)
+      const uint32_t sa = pos_of_freq(q, logL), sb = L + pos_of_freq(L - 1 - q, logL);
+      pointwise_pair<F61>(P, sa, sb, cmul<F61>(ua61, T.v61[q]));
+      pointwise_pair<F31>(P, sa, sb, cmul<F31>(ua31, T.v31[q]));
+    } else if (q < (L >> 1)) {                                          // row H1/2: k2 = q <-> L - 1 - q
+      const uint32_t sa = L + pos_of_freq(q, logL), sb = L + pos_of_freq(L - 1 - q, logL);
+      pointwise_pair<F61>(P, sa, sb, cmul<F61>(ub61, T.v61[q]));
+      pointwise_pair<F31>(P, sa, sb, cmul<F31>(ub31, T.v31[q]));
+    } else {                                                            // row 0: k2 = q' <-> L - q'
+      const uint32_t qq = q - (L >> 1);
+      if (qq == 0) {
+        pointwise_zero<F61>(P, 0); pointwise_zero<F31>(P, 0);
+        const uint32_t sm = pos_of_freq(L >> 1, logL);
+        pointwise_self<F61>(P, sm, T.v61[L >> 1]); pointwise_self<F31>(P, sm, T.v31[L >> 1]);
+      } else {
+        const uint32_t sa = pos_of_freq(qq, logL), sb = pos_of_freq(L - qq, logL);
+        pointwise_pair<F61>(P, sa, sb, T.v61[qq]);
+        pointwise_pair<F31>(P, sa, sb, T.v31[qq]);
+      }
+    }
+  }
+  transform_both<true>(P, tid, logL, T.w2_61, T.w2_31);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t e = tid + 256u * it, r = e >> logL, i = e & (L - 1);
+    const size_t addr = size_t(r ? k1b : k1a) * L + i;
+    z61[addr] = Slot<F61>::get(P, e); z31[addr] = Slot<F31>::get(P, e);
+  }
+}
+
+}  // namespace crt
+}  // namespace mi355

@@ -20,8 +20,12 @@ def CrtEngine(*a, **k):
 
 # (exponent, odd radix, forced words or 0, plan): single-pass rows, two-pass rows (h2 forces the four-step split at small sizes)
 CASES = [(521, 1, 0, None), (607, 3, 0, None), (1279, 9, 0, None), (9941, 9, 0, None), (9941, 3, 0, "h2=2"), (11213, 9, 9 << 6, "h2=3"),
-         (44497, 1, 0, "h2=4"), (86243, 9, 0, "h2=5"), (216091, 3, 0, None), (216091, 9, 9 << 11, "h2=6"), (1257787, 9, 0, None),
-         (3021377, 1, 0, None), (3021377, 3, 3 << 17, "h2=7")]
+         (44497, 1, 0, "h2=4"), (86243, 9, 0, "h2=5"), (216091, 3, 0, None), (400063, 9, 9 << 11, "h2=6"), (1257787, 9, 0, None),
+         (3021377, 1, 0, None), (6972593, 3, 3 << 17, "h2=7"),
+         # rows of 1024 and columns of 2 .. 256: the radix-8 kernel set (crt_rows.hpp) with every last-step radix
+         # (forced sizes keep at least 15 bits per word: the run-wise carry needs them, see the constructor's check)
+         (756839, 9, 9 << 12, None), (216091, 1, 1 << 13, None), (1257787, 3, 3 << 14, None), (6972593, 9, 9 << 15, None), (1398269, 1, 1 << 16, None),
+         (6972593, 3, 3 << 17, None), (37156667, 9, 9 << 18, None), (13466917, 1, 1 << 19, None)]
 
 
 @pytest.mark.parametrize("p,odd,n,plan", CASES)
@@ -38,6 +42,22 @@ def test_square_mul_matches_the_oracle_digit_for_digit(p, odd, n, plan):
             assert np.array_equal(e.digits(), o.digits()), (p, odd, plan, it)
         assert np.array_equal(e.words(), o.words())
         assert e.res64() == o.value() & ((1 << 64) - 1)
+
+
+def test_both_kernel_sets_agree(monkeypatch):
+    """the same squarings on the radix-8 row kernels and on the generic LDS radix-2 ones (MI355_CRT_KERNELS=generic)"""
+    p, odd, n = 13466917, 9, 9 << 16
+    rng = np.random.default_rng(5)
+    with CrtEngine(p, odd, n) as e:
+        assert e.describe().endswith("radix8")
+        monkeypatch.setenv("MI355_CRT_KERNELS", "generic")
+        with CrtEngine(p, odd, n) as g:
+            assert g.describe().endswith("generic")
+            start = rng.integers(0, 1 << 20, n, dtype=np.uint64)
+            e.set_digits(start); g.set_digits(start)
+            for a in (1, 3, 1):
+                e.square_mul(a); g.square_mul(a)
+                assert np.array_equal(e.digits(), g.digits())
 
 
 @pytest.mark.parametrize("p,odd", [(127, 1), (521, 3), (1279, 9), (2203, 9), (2281, 3)])
@@ -60,6 +80,12 @@ def test_lucas_lehmer_verdicts(p, odd):
                 if i % 97 == 0 or i == q - 3:
                     assert e.get_int() == s, (q, i)
             assert (e.get_int() == 0) == prime
+
+
+def test_sizes_with_too_few_bits_per_word_are_refused():
+    from prmers_amd import EngineError
+    with pytest.raises(EngineError, match="bits per word"):
+        CrtEngine(216091, 9, 9 << 15)
 
 
 def test_set_sub_and_all_ones():

@@ -54,7 +54,7 @@ def test_c_abi_exports_and_no_gpu_behaviour():
         pytest.skip("libmi355_engine.so not built")
     lib = ctypes.CDLL(E.LIB_PATH)
     header = open(os.path.join(ROOT, "include", "mi355_engine.h")).read()
-    declared = sorted(set(re.findall(r"\b(mi355_engine_[a-z0-9_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(mi355_(?:engine|crt)_[a-z0-9_]+)\s*\(", header)))
     assert declared, "no declarations found"
     for name in declared:
         getattr(lib, name)
@@ -67,6 +67,9 @@ def test_c_abi_exports_and_no_gpu_behaviour():
     if not torch.cuda.is_available():
         with pytest.raises(E.EngineError, match="no CPU fallback|HIP"):
             E.Engine(127, 2)
+        with pytest.raises(E.EngineError, match="no CPU fallback|HIP"):
+            E.CrtEngine(1279, 9)
+    assert lib.mi355_crt_kernel_count() == 6
 
 
 def _build_adapter(td):
