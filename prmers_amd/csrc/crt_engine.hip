@@ -35,8 +35,9 @@ constexpr uint32_t kPassElems = 2048;   // complex values of one work-group of a
 
 struct Grid {
   uint32_t odd, ln, m, h, logh, logH1, logH2, minv;   // h = 2^logh = H1 H2; minv = m^-1 mod odd
-  uint64_t r61[9], r61i[9], s61;                      // odd-root powers, their inverses, 1 / (odd h)
-  uint32_t r31[9], r31i[9], s31;
+  uint64_t r61[9], r61i[9], s61, c3_61;               // odd-root powers r^e, their inverses, 1 / (odd h), (w3 - w3^2) / 2
+  uint32_t r31[9], r31i[9], s31, c3_31;
+  uint32_t mm, pm, lpm61, lpm31;                      // m mod odd; p m mod n and its images l61 (p m) mod 61, l31 (p m) mod 31
 };
 
 template <class F>
@@ -46,67 +47,113 @@ __device__ __forceinline__ typename F::C tw_m(const typename F::C* __restrict__ 
 
 __device__ __forceinline__ uint32_t brev(uint32_t i, uint32_t bits) { return bits ? (__brev(i) >> (32 - bits)) : 0u; }
 
-// ---- front: weight + odd axis --------------------------------------------------------------------------------------------
-// thread = slot s of every row: the 2 odd digits b + m t (b = 2s, 2s + 1; t < odd) are exactly the grid column pair, digit
-// b + m t at row a = (b + m t) mod odd.  Weight exponents come from the digit's own p j mod n (DigitWalk::start).
-template <int ODD>
-__global__ void __launch_bounds__(256) k_front(Geom g, Grid gr, const uint64_t* __restrict__ x, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
-  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= gr.h) return;
-  F61::C in61[ODD]; F31::C in31[ODD];
+// ---- odd axis: DFT of length 1, 3 or 9 with scalar roots --------------------------------------------------------------------
+// DFT-3 with w + w^2 = -1: y0 = x0 + (x1 + x2), y1,2 = x0 - (x1 + x2) / 2 +- c (x1 - x2), c = (w - w^2) / 2: one scalar product.
+// DFT-9 = 3 x 3 (Cooley-Tukey): three DFT-3 over a1 (a = 3 a1 + a0), twiddles r^(a0 k0) (four non-trivial), three DFT-3 over a0
+// -> X[k0 + 3 k1]: 10 scalar-times-complex products instead of the 64 of the direct sums.  (Reference: fft-middle.cl:663-720.)
+template <class F>
+__device__ __forceinline__ void dft3(typename F::C& x0, typename F::C& x1, typename F::C& x2, typename F::S c) {
+  using C = typename F::C;
+  const C t1 = cadd<F>(x1, x2), t2 = cscale<F>(csub<F>(x1, x2), c);
+  const C u = csub<F>(x0, chalf<F>(t1));
+  x0 = cadd<F>(x0, t1); x1 = cadd<F>(u, t2); x2 = csub<F>(u, t2);
+}
+template <class F, int ODD>
+__device__ __forceinline__ void dft_odd(typename F::C (&x)[ODD], const typename F::S* __restrict__ r /* r^e, e < 9 */, typename F::S c3) {
+  using C = typename F::C;
+  if (ODD == 3) {
+    dft3<F>(x[0], x[1], x[2], c3);
+  } else if (ODD == 9) {
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const uint32_t b = 2 * s + half;
+    for (int a0 = 0; a0 < 3; ++a0) dft3<F>(x[a0], x[a0 + 3], x[a0 + 6], c3);     // x[a0 + 3 k0] <- Y[a0][k0]
+    x[1 + 3] = cscale<F>(x[1 + 3], r[1]); x[1 + 6] = cscale<F>(x[1 + 6], r[2]);
+    x[2 + 3] = cscale<F>(x[2 + 3], r[2]); x[2 + 6] = cscale<F>(x[2 + 6], r[4]);
+    C y[9];
 #pragma unroll
-    for (int a = 0; a < ODD; ++a) {
-      const uint32_t t = ODD > 1 ? ((uint32_t(a) + ODD - b % ODD) % ODD) * gr.minv % ODD : 0u;
-      const uint32_t j = b + gr.m * t;
-      const uint64_t v = x[j];
-      DigitWalk dw; dw.start(g, j);
-      const uint64_t v61 = rot61(red61(v), dw.weight61());
-      const uint32_t v31 = rot31(red31(v), dw.weight31());
-      if (half == 0) { in61[a].re = v61; in31[a].re = v31; } else { in61[a].im = v61; in31[a].im = v31; }
+    for (int k0 = 0; k0 < 3; ++k0) {
+      C z0 = x[3 * k0], z1 = x[3 * k0 + 1], z2 = x[3 * k0 + 2];
+      dft3<F>(z0, z1, z2, c3);
+      y[k0] = z0; y[k0 + 3] = z1; y[k0 + 6] = z2;                                // X[k0 + 3 k1]
     }
-  }
 #pragma unroll
-  for (int ka = 0; ka < ODD; ++ka) {
-    F61::C o61 = in61[0]; F31::C o31 = in31[0];
-#pragma unroll
-    for (int a = 1; a < ODD; ++a) {
-      const int e = (a * ka) % ODD;
-      o61 = cadd<F61>(o61, e ? cscale<F61>(in61[a], gr.r61[e]) : in61[a]);
-      o31 = cadd<F31>(o31, e ? cscale<F31>(in31[a], gr.r31[e]) : in31[a]);
-    }
-    Z61[size_t(ka) * gr.h + s] = o61; Z31[size_t(ka) * gr.h + s] = o31;
+    for (int k = 0; k < 9; ++k) x[k] = y[k];
   }
 }
 
-// ---- back: inverse odd axis, 1 / (odd h), scatter to logical order -------------------------------------------------------
+// weight exponents of the digits b + m t, t = 0 .. odd-1, kept incrementally: s = p j mod n advances by p m mod n
+struct ColumnWalk {
+  uint32_t s, A61, A31;
+  __device__ __forceinline__ void step_t(const Geom& g, const Grid& gr) {
+    uint32_t sn = s + gr.pm;
+    A61 += gr.lpm61; A31 += gr.lpm31;
+    if (sn >= g.n) { sn -= g.n; A61 += 60; A31 += 30; }
+    s = sn;
+    A61 = A61 >= 122 ? A61 - 122 : (A61 >= 61 ? A61 - 61 : A61);
+    A31 = A31 >= 62 ? A31 - 62 : (A31 >= 31 ? A31 - 31 : A31);
+  }
+};
+
+// ---- front: weight + odd axis --------------------------------------------------------------------------------------------
+// thread = slot s (b = 2s, 2s + 1) of every row.  For t = 0 .. odd-1 the digit pair (b + m t) is one 16-byte load; digit j belongs to
+// row a = j mod odd, which changes with t and b: the weighted values go through a private LDS column ([a][thread], no barrier) to
+// reach the registers of the odd-axis DFT in row order.
+template <int ODD>
+__global__ void __launch_bounds__(256) k_front(Geom g, Grid gr, const uint64_t* __restrict__ x, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
+  __shared__ uint64_t S61[2 * ODD][256];
+  __shared__ uint32_t S31[2 * ODD][256];
+  const uint32_t tid = threadIdx.x, s = blockIdx.x * 256 + tid;
+  if (s >= gr.h) return;
+  const uint32_t b = 2 * s;
+  DigitWalk d0; d0.start(g, b);
+  ColumnWalk w{d0.s, d0.A61, d0.A31};
+  uint32_t a = b % ODD;                                   // row of digit b + m t
+#pragma unroll
+  for (int t = 0; t < ODD; ++t) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(x + b + size_t(gr.m) * t);
+    DigitWalk d; d.s = w.s; d.A61 = w.A61; d.A31 = w.A31;
+    const uint32_t a1 = (a + 1 == ODD) ? 0 : a + 1;       // digit b + 1 + m t sits one row further
+    S61[2 * a][tid] = rot61(red61(v.x), d.weight61()); S31[2 * a][tid] = rot31(red31(v.x), d.weight31());
+    d.next(g);
+    S61[2 * a1 + 1][tid] = rot61(red61(v.y), d.weight61()); S31[2 * a1 + 1][tid] = rot31(red31(v.y), d.weight31());
+    w.step_t(g, gr);
+    a += gr.mm; if (a >= ODD) a -= ODD;
+  }
+  F61::C in61[ODD]; F31::C in31[ODD];
+#pragma unroll
+  for (int k = 0; k < ODD; ++k) { in61[k] = {S61[2 * k][tid], S61[2 * k + 1][tid]}; in31[k] = {S31[2 * k][tid], S31[2 * k + 1][tid]}; }
+  dft_odd<F61, ODD>(in61, gr.r61, gr.c3_61);
+  dft_odd<F31, ODD>(in31, gr.r31, gr.c3_31);
+#pragma unroll
+  for (int ka = 0; ka < ODD; ++ka) { Z61[size_t(ka) * gr.h + s] = in61[ka]; Z31[size_t(ka) * gr.h + s] = in31[ka]; }
+}
+
+// ---- back: inverse odd axis, 1 / (odd h), to logical order (16-byte and 8-byte stores of digit pairs) ----------------------
 template <int ODD>
 __global__ void __launch_bounds__(256) k_back(Grid gr, const F61::C* __restrict__ Z61, const F31::C* __restrict__ Z31, uint64_t* __restrict__ out61,
                                               uint32_t* __restrict__ out31) {
-  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  __shared__ uint64_t S61[2 * ODD][256];
+  __shared__ uint32_t S31[2 * ODD][256];
+  const uint32_t tid = threadIdx.x, s = blockIdx.x * 256 + tid;
   if (s >= gr.h) return;
   F61::C in61[ODD]; F31::C in31[ODD];
 #pragma unroll
-  for (int a = 0; a < ODD; ++a) { in61[a] = Z61[size_t(a) * gr.h + s]; in31[a] = Z31[size_t(a) * gr.h + s]; }
+  for (int k = 0; k < ODD; ++k) { in61[k] = Z61[size_t(k) * gr.h + s]; in31[k] = Z31[size_t(k) * gr.h + s]; }
+  dft_odd<F61, ODD>(in61, gr.r61i, F61::neg(gr.c3_61));
+  dft_odd<F31, ODD>(in31, gr.r31i, F31::neg(gr.c3_31));
 #pragma unroll
-  for (int a = 0; a < ODD; ++a) {
-    F61::C o61 = in61[0]; F31::C o31 = in31[0];
+  for (int k = 0; k < ODD; ++k) {
+    const F61::C o61 = cscale<F61>(in61[k], gr.s61); const F31::C o31 = cscale<F31>(in31[k], gr.s31);
+    S61[2 * k][tid] = o61.re; S61[2 * k + 1][tid] = o61.im; S31[2 * k][tid] = o31.re; S31[2 * k + 1][tid] = o31.im;
+  }
+  const uint32_t b = 2 * s;
+  uint32_t a = b % ODD;
 #pragma unroll
-    for (int ka = 1; ka < ODD; ++ka) {
-      const int e = (a * ka) % ODD;
-      o61 = cadd<F61>(o61, e ? cscale<F61>(in61[ka], gr.r61i[e]) : in61[ka]);
-      o31 = cadd<F31>(o31, e ? cscale<F31>(in31[ka], gr.r31i[e]) : in31[ka]);
-    }
-    o61 = cscale<F61>(o61, gr.s61); o31 = cscale<F31>(o31, gr.s31);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const uint32_t b = 2 * s + half;
-      const uint32_t t = ODD > 1 ? ((uint32_t(a) + ODD - b % ODD) % ODD) * gr.minv % ODD : 0u;
-      const uint32_t j = b + gr.m * t;
-      out61[j] = half ? o61.im : o61.re; out31[j] = half ? o31.im : o31.re;
-    }
+  for (int t = 0; t < ODD; ++t) {
+    const uint32_t a1 = (a + 1 == ODD) ? 0 : a + 1;
+    const size_t j = b + size_t(gr.m) * t;
+    *reinterpret_cast<ulonglong2*>(out61 + j) = make_ulonglong2(S61[2 * a][tid], S61[2 * a1 + 1][tid]);
+    *reinterpret_cast<uint2*>(out31 + j) = make_uint2(S31[2 * a][tid], S31[2 * a1 + 1][tid]);
+    a += gr.mm; if (a >= ODD) a -= ODD;
   }
 }
 
@@ -363,6 +410,15 @@ CrtEngine::CrtEngine(uint32_t p, uint32_t odd, size_t n_forced, int device, cons
     for (unsigned k = 0; k < 9; ++k) {
       gr.r61[k] = pow61(r61, k % odd); gr.r61i[k] = pow61(r61, (odd - k % odd) % odd);
       gr.r31[k] = pow31(r31, k % odd); gr.r31i[k] = pow31(r31, (odd - k % odd) % odd);
+    }
+    {
+      const unsigned cube = odd == 9 ? 3 : 1;            // w3 = r^3 for radix 9, r itself for radix 3
+      const uint64_t w61 = gr.r61[cube % 9], w61sq = crt::mul61(w61, w61);
+      const uint32_t w31 = gr.r31[cube % 9], w31sq = crt::mul31(w31, w31);
+      gr.c3_61 = odd > 1 ? F61::half(F61::sub(w61, w61sq)) : 0; gr.c3_31 = odd > 1 ? F31::half(F31::sub(w31, w31sq)) : 0;
+      gr.mm = gr.m % odd;
+      gr.pm = uint32_t((uint64_t(p) * gr.m) % n);
+      gr.lpm61 = uint32_t(uint64_t(im.g.l61) * (gr.pm % 61) % 61); gr.lpm31 = uint32_t(uint64_t(im.g.l31) * (gr.pm % 31) % 31);
     }
     gr.s61 = pow61((uint64_t(odd) * gr.h) % M61, M61 - 2); gr.s31 = pow31(uint32_t((uint64_t(odd) * gr.h) % M31), M31 - 2);
 
