@@ -372,8 +372,8 @@ struct CrtEngine::Impl {
   uint64_t *w61 = nullptr, *carry = nullptr, *residual = nullptr;
   uint32_t* w31 = nullptr;
   bool fast = false;              // crt_rows.hpp kernels (rows of 1024, columns of 2 .. 2048)
-  F61::C *W1_61 = nullptr, *W2_61 = nullptr, *V61 = nullptr;
-  F31::C *W1_31 = nullptr, *W2_31 = nullptr, *V31 = nullptr;
+  F61::C *W1_61 = nullptr, *W2_61 = nullptr, *V61 = nullptr, *LO61 = nullptr, *HI61 = nullptr;
+  F31::C *W1_31 = nullptr, *W2_31 = nullptr, *V31 = nullptr, *LO31 = nullptr, *HI31 = nullptr;
   hipEvent_t ev[kKernels + 1] = {};
   std::vector<uint8_t> width;
 };
@@ -460,6 +460,8 @@ CrtEngine::CrtEngine(uint32_t p, uint32_t odd, size_t n_forced, int device, cons
         upload(H1, m / H1, im.W1_61, im.W1_31);
         upload(H2, m / H2, im.W2_61, im.W2_31);
         upload(H2, H1, im.V61, im.V31);
+        upload(1024, 1, im.LO61, im.LO31);                 // m >= 2^12 on this path
+        upload(m >> 10, 1024, im.HI61, im.HI31);
       }
     }
     im.width.resize(n);
@@ -479,7 +481,8 @@ void CrtEngine::release() {
   for (void* q : {static_cast<void*>(im.x), static_cast<void*>(im.Z61), static_cast<void*>(im.Z31), static_cast<void*>(im.U61), static_cast<void*>(im.U31),
                   static_cast<void*>(im.w61), static_cast<void*>(im.w31), static_cast<void*>(im.carry), static_cast<void*>(im.residual),
                   static_cast<void*>(im.W1_61), static_cast<void*>(im.W2_61), static_cast<void*>(im.V61), static_cast<void*>(im.W1_31),
-                  static_cast<void*>(im.W2_31), static_cast<void*>(im.V31)})
+                  static_cast<void*>(im.W2_31), static_cast<void*>(im.V31), static_cast<void*>(im.LO61), static_cast<void*>(im.HI61),
+                  static_cast<void*>(im.LO31), static_cast<void*>(im.HI31)})
     if (q) (void)hipFree(q);
   for (auto& e : im.ev) if (e) (void)hipEventDestroy(e);
   if (im.stream) (void)hipStreamDestroy(im.stream);
@@ -539,7 +542,7 @@ void CrtEngine::launch_square(uint32_t a, bool timed) {
   }
   mark();
   if (im.fast) {
-    const crt::FastTables T{im.W1_61, im.W2_61, im.V61, im.U61, im.W1_31, im.W2_31, im.V31, im.U31};
+    const crt::FastTables T{im.W1_61, im.W2_61, im.V61, im.U61, im.LO61, im.HI61, im.W1_31, im.W2_31, im.V31, im.U31, im.LO31, im.HI31};
     const uint32_t CA = crt::kFastSlots >> gr.logH1, gcols = gr.odd * ((1u << gr.logH2) / CA), gmid = gr.odd * (1u << gr.logH1) / 2;
     hipLaunchKernelGGL((crt::k_cols_fast<false>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
     mark();

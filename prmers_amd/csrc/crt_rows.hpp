@@ -18,9 +18,10 @@ constexpr uint32_t kFastSlots = 2048;
 constexpr uint32_t kFastPlane = kFastSlots + kFastSlots / 16;   // skewed by a + a / 16
 constexpr uint32_t kFastLdsBytes = kFastPlane * 8 * 3;
 
-struct FastTables {   // per field: omega_L^x for the two pass lengths (x < L), omega_m^(H1 k2) (k2 < H2), omega_m^k (k <= h)
-  const F61::C *w1_61, *w2_61, *v61, *u61;
-  const F31::C *w1_31, *w2_31, *v31, *u31;
+struct FastTables {   // per field: omega_L^x for the two pass lengths (x < L), omega_m^(H1 k2) (k2 < H2), omega_m^k (k <= h),
+                      // and the two-level table of the four-step twiddles: omega_m^e = lo[e & 1023] * hi[e >> 10] (e < m)
+  const F61::C *w1_61, *w2_61, *v61, *u61, *lo61, *hi61;
+  const F31::C *w1_31, *w2_31, *v31, *u31, *lo31, *hi31;
 };
 
 struct Planes { uint64_t* re; uint64_t* im; uint2* c3; };
@@ -49,14 +50,77 @@ __device__ __forceinline__ typename F::C mul_w8(typename F::C a) {
 template <class F, bool INV>
 __device__ __forceinline__ typename F::C mul_w4(typename F::C a) { return INV ? cdiv_i<F>(a) : cmul_i<F>(a); }   // omega_4 = i
 
+// ---- Z/M61 without a reduction per operation -------------------------------------------------------------------------------------
+// M61 leaves three spare bits in a 64-bit register, exactly what the three levels of a radix-8 butterfly need: with canonical inputs
+// (<= M61) the sums are plain 64-bit additions (one v_lshl_add_u64) and a difference is a + (K - b) with K = M61, 2 M61, 4 M61 at the
+// three levels, so every intermediate stays <= 8 M61 = 2^64 - 8.  The products fold their operands once ((v & M61) + (v >> 61) <= M61 + 7),
+// split them into 31-bit limbs and accumulate both products of a complex component limb-wise in 64-bit multiply-adds
+// (re = a c + b (M61 - d): M61 - d is a bit complement of d's limbs), with ONE reduction per component: 16 multiply-adds and two
+// reductions per complex product instead of four full multiplications with a reduction each.
+constexpr uint64_t K1 = M61, K2 = 2 * M61, K4 = 4 * M61;
+__device__ __forceinline__ uint64_t fold61(uint64_t v) { return (v & M61) + (v >> 61); }                    // any v -> <= M61 + 7
+__device__ __forceinline__ uint64_t canon61(uint64_t v) { v = fold61(v); return v >= M61 ? v - M61 : v; }  // any v -> [0, M61)
+__device__ __forceinline__ uint64_t shl30_61(uint64_t v) { return ((v & 0x7fffffffull) << 30) + (v >> 31); } // v 2^30, any v -> < 2^61 + 2^33
+struct Lz61 { uint64_t re, im; };   // lazy complex value; bounds are tracked in the comments of the callers
+
+template <bool INV, uint64_t K>   // x * omega_8 (or its conjugate); components <= K on entry, <= 2 M61 on exit (K <= 2 M61)
+__device__ __forceinline__ Lz61 lz_w8(Lz61 a) {
+  if (!INV) return {shl30_61(a.re + (K - a.im)), shl30_61(a.re + a.im)};
+  return {shl30_61(a.re + a.im), shl30_61(a.im + (K - a.re))};
+}
+template <bool INV, uint64_t K>   // x * i (or / i); components <= K stay <= K
+__device__ __forceinline__ Lz61 lz_w4(Lz61 a) { return INV ? Lz61{a.im, K - a.re} : Lz61{K - a.im, a.re}; }
+template <uint64_t K> __device__ __forceinline__ Lz61 lz_add(Lz61 a, Lz61 b) { return {a.re + b.re, a.im + b.im}; }
+template <uint64_t K> __device__ __forceinline__ Lz61 lz_sub(Lz61 a, Lz61 b) { return {a.re + (K - b.re), a.im + (K - b.im)}; }   // b <= K
+
+// canonical in (<= M61), lazy out (<= 8 M61 for R = 8, 4 M61 for R = 4, 2 M61 for R = 2)
+template <int R, bool INV>
+__device__ __forceinline__ void bfly61(Lz61 (&x)[R]) {
+  if constexpr (R == 2) {
+    const Lz61 a = lz_add<K1>(x[0], x[1]), b = lz_sub<K1>(x[0], x[1]);
+    x[0] = a; x[1] = b;
+  } else if constexpr (R == 4) {
+    const Lz61 a0 = lz_add<K1>(x[0], x[2]), a1 = lz_add<K1>(x[1], x[3]), b0 = lz_sub<K1>(x[0], x[2]), b1 = lz_w4<INV, K2>(lz_sub<K1>(x[1], x[3]));
+    x[0] = lz_add<K2>(a0, a1); x[2] = lz_sub<K2>(a0, a1); x[1] = lz_add<K2>(b0, b1); x[3] = lz_sub<K2>(b0, b1);
+  } else {
+    const Lz61 a0 = lz_add<K1>(x[0], x[4]), a1 = lz_add<K1>(x[1], x[5]), a2 = lz_add<K1>(x[2], x[6]), a3 = lz_add<K1>(x[3], x[7]);           // <= 2 M61
+    const Lz61 b0 = lz_sub<K1>(x[0], x[4]), b1 = lz_w8<INV, K2>(lz_sub<K1>(x[1], x[5])), b2 = lz_w4<INV, K2>(lz_sub<K1>(x[2], x[6])),
+              b3 = lz_w4<INV, K2>(lz_w8<INV, K2>(lz_sub<K1>(x[3], x[7])));                                                                  // <= 2 M61
+    const Lz61 c0 = lz_add<K2>(a0, a2), c1 = lz_add<K2>(a1, a3), d0 = lz_sub<K2>(a0, a2), d1 = lz_w4<INV, K4>(lz_sub<K2>(a1, a3));            // <= 4 M61
+    const Lz61 e0 = lz_add<K2>(b0, b2), e1 = lz_add<K2>(b1, b3), f0 = lz_sub<K2>(b0, b2), f1 = lz_w4<INV, K4>(lz_sub<K2>(b1, b3));
+    x[0] = lz_add<K4>(c0, c1); x[4] = lz_sub<K4>(c0, c1); x[2] = lz_add<K4>(d0, d1); x[6] = lz_sub<K4>(d0, d1);                               // <= 8 M61
+    x[1] = lz_add<K4>(e0, e1); x[5] = lz_sub<K4>(e0, e1); x[3] = lz_add<K4>(f0, f1); x[7] = lz_sub<K4>(f0, f1);
+  }
+}
+
+// (a + i b)(c + i d) or, CONJ, (a + i b)(c - i d): a, b <= M61 + 7 (folded), c, d canonical; canonical result
+template <bool CONJ>
+__device__ __forceinline__ F61::C cmul61(Lz61 x, F61::C w) {
+  const uint32_t a0 = uint32_t(x.re) & 0x7fffffffu, a1 = uint32_t(x.re >> 31), b0 = uint32_t(x.im) & 0x7fffffffu, b1 = uint32_t(x.im >> 31);
+  const uint32_t c0 = uint32_t(w.re) & 0x7fffffffu, c1 = uint32_t(w.re >> 31);
+  uint32_t d0 = uint32_t(w.im) & 0x7fffffffu, d1 = uint32_t(w.im >> 31);
+  uint32_t n0 = d0 ^ 0x7fffffffu, n1 = d1 ^ 0x3fffffffu;                        // limbs of M61 - d
+  if (CONJ) { uint32_t t = d0; d0 = n0; n0 = t; t = d1; d1 = n1; n1 = t; }
+  const uint64_t P0 = uint64_t(a0) * c0 + uint64_t(b0) * n0;                      // < 2^63
+  const uint64_t P1 = uint64_t(a0) * c1 + uint64_t(a1) * c0 + uint64_t(b0) * n1 + uint64_t(b1) * n0;   // < 2^63
+  const uint64_t P2 = uint64_t(a1) * c1 + uint64_t(b1) * n1;                      // <= 2^61
+  const uint64_t Q0 = uint64_t(a0) * d0 + uint64_t(b0) * c0;
+  const uint64_t Q1 = uint64_t(a0) * d1 + uint64_t(a1) * d0 + uint64_t(b0) * c1 + uint64_t(b1) * c0;
+  const uint64_t Q2 = uint64_t(a1) * d1 + uint64_t(b1) * c1;
+  // P0 + P1 2^31 + P2 2^62 with 2^61 = 1: P1 = l + h 2^30 -> l 2^31 + h; P2 2^62 -> 2 P2; the sum stays below 2^64
+  const uint64_t S = P0 + (P2 << 1) + (P1 >> 30) + (uint64_t(uint32_t(P1) & 0x3fffffffu) << 31);
+  const uint64_t T = Q0 + (Q2 << 1) + (Q1 >> 30) + (uint64_t(uint32_t(Q1) & 0x3fffffffu) << 31);
+  return {canon61(S), canon61(T)};
+}
+
 // out[k] = sum_q in[q] w^(qk), w = omega_R (forward) or its conjugate (INV, unnormalised); natural order in and out
 template <class F, int R, bool INV>
 __device__ __forceinline__ void bfly(typename F::C (&x)[R]) {
   using C = typename F::C;
-  if (R == 2) {
+  if constexpr (R == 2) {
     const C a = cadd<F>(x[0], x[1]), b = csub<F>(x[0], x[1]);
     x[0] = a; x[1] = b;
-  } else if (R == 4) {
+  } else if constexpr (R == 4) {
     const C a0 = cadd<F>(x[0], x[2]), a1 = cadd<F>(x[1], x[3]), b0 = csub<F>(x[0], x[2]), b1 = mul_w4<F, INV>(csub<F>(x[1], x[3]));
     x[0] = cadd<F>(a0, a1); x[2] = csub<F>(a0, a1); x[1] = cadd<F>(b0, b1); x[3] = csub<F>(b0, b1);
   } else {
@@ -100,8 +164,38 @@ __device__ __forceinline__ void step(const Planes& P, uint32_t tid, uint32_t log
   }
 }
 
-// radices of a transform of length 2^logL: radix 8 while three bits are left, then the rest
-__device__ __forceinline__ uint32_t step_bits(uint32_t logS) { return logS >= 3 ? 3u : logS; }
+// the same step for Z/M61[i] on the lazy forms above: canonical in LDS, one canonicalisation per value and step
+template <int LR, bool INV>
+__device__ __forceinline__ void step61(const Planes& P, uint32_t tid, uint32_t logL, uint32_t logS, const F61::C* __restrict__ WL) {
+  constexpr int R = 1 << LR, G = 8 / R;
+  const uint32_t logSr = logS - LR;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const uint32_t bf = tid * G + g;
+    const uint32_t c = bf >> (logL - LR), bfl = bf & ((1u << (logL - LR)) - 1);
+    const uint32_t j = bfl & ((1u << logSr) - 1), blk = bfl >> logSr;
+    const uint32_t base = (c << logL) + (blk << logS) + j;
+    Lz61 x[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) { const F61::C v = Slot<F61>::get(P, base + (uint32_t(q) << logSr)); x[q] = {v.re, v.im}; }
+    if (INV && logSr) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) { const F61::C v = cmul61<true>(x[k], WL[(j * uint32_t(k)) << (logL - logS)]); x[k] = {v.re, v.im}; }
+    }
+    bfly61<R, INV>(x);
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      F61::C v;
+      if (!INV && logSr && q) v = cmul61<false>(Lz61{fold61(x[q].re), fold61(x[q].im)}, WL[(j * uint32_t(q)) << (logL - logS)]);
+      else v = {canon61(x[q].re), canon61(x[q].im)};
+      Slot<F61>::put(P, base + (uint32_t(q) << logSr), v);
+    }
+  }
+}
+
+// radices of a transform of length 2^logL: the odd bits first (radix 2 or 4), then radix 8 -- the last step needs no twiddles, so it
+// should be a wide one (1024 points: 2.8.8.8 multiplies 2.25 slots in 8 by a table twiddle per direction, 8.8.8.2 would 2.6)
+__device__ __forceinline__ uint32_t step_bits(uint32_t logS) { return (logS % 3u) ? (logS % 3u) : 3u; }
 
 template <bool INV>
 __device__ __forceinline__ void transform_both(const Planes& P, uint32_t tid, uint32_t logL, const F61::C* __restrict__ W61, const F31::C* __restrict__ W31) {
@@ -112,9 +206,9 @@ __device__ __forceinline__ void transform_both(const Planes& P, uint32_t tid, ui
     const uint32_t logS = sizes[INV ? ns - 1 - t : t];
     const uint32_t lr = step_bits(logS);
     __syncthreads();
-    if (lr == 3) { step<F61, 3, INV>(P, tid, logL, logS, W61); step<F31, 3, INV>(P, tid, logL, logS, W31); }
-    else if (lr == 2) { step<F61, 2, INV>(P, tid, logL, logS, W61); step<F31, 2, INV>(P, tid, logL, logS, W31); }
-    else { step<F61, 1, INV>(P, tid, logL, logS, W61); step<F31, 1, INV>(P, tid, logL, logS, W31); }
+    if (lr == 3) { step61<3, INV>(P, tid, logL, logS, W61); step<F31, 3, INV>(P, tid, logL, logS, W31); }
+    else if (lr == 2) { step61<2, INV>(P, tid, logL, logS, W61); step<F31, 2, INV>(P, tid, logL, logS, W31); }
+    else { step61<1, INV>(P, tid, logL, logS, W61); step<F31, 1, INV>(P, tid, logL, logS, W31); }
   }
   __syncthreads();
 }
@@ -153,10 +247,10 @@ __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C
     const size_t addr = size_t(i) * H2 + col0 + c;
     F61::C a = z61[addr]; F31::C b = z31[addr];
     uint32_t slot = (c << logL) + i;
-    if (INV) {
-      const uint32_t tw = 2u * i * (col0 + c);                          // conj(omega_h^(k1 i2))
-      a = cmul<F61>(a, cconj<F61>(tw < gr.h ? T.u61[tw] : cneg<F61>(T.u61[tw - gr.h])));
-      b = cmul<F31>(b, cconj<F31>(tw < gr.h ? T.u31[tw] : cneg<F31>(T.u31[tw - gr.h])));
+    if (INV) {   // conj(omega_h^(k1 i2)) from the two small tables (a gather from the full table costs two 128-byte lines a slot)
+      const uint32_t tw = 2u * i * (col0 + c);
+      a = cmul61<true>(Lz61{a.re, a.im}, T.lo61[tw & 1023]); a = cmul61<true>(Lz61{a.re, a.im}, T.hi61[tw >> 10]);
+      b = cmul<F31>(cmul<F31>(b, cconj<F31>(T.lo31[tw & 1023])), cconj<F31>(T.hi31[tw >> 10]));
       slot = (c << logL) + pos_of_freq(i, logL);
     }
     Slot<F61>::put(P, slot, a); Slot<F31>::put(P, slot, b);
@@ -169,8 +263,8 @@ __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C
     F61::C a = Slot<F61>::get(P, slot); F31::C b = Slot<F31>::get(P, slot);
     if (!INV) {
       const uint32_t tw = 2u * i * (col0 + c);
-      a = cmul<F61>(a, tw < gr.h ? T.u61[tw] : cneg<F61>(T.u61[tw - gr.h]));
-      b = cmul<F31>(b, tw < gr.h ? T.u31[tw] : cneg<F31>(T.u31[tw - gr.h]));
+      a = cmul61<false>(Lz61{a.re, a.im}, T.lo61[tw & 1023]); a = cmul61<false>(Lz61{a.re, a.im}, T.hi61[tw >> 10]);
+      b = cmul<F31>(cmul<F31>(b, T.lo31[tw & 1023]), T.hi31[tw >> 10]);
     }
     const size_t addr = size_t(i) * H2 + col0 + c;
     z61[addr] = a; z31[addr] = b;
