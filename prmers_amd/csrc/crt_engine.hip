@@ -568,7 +568,7 @@ void CrtEngine::launch_square(uint32_t a, bool timed) {
     default: hipLaunchKernelGGL((crt::k_back<9>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;
   }
   mark();
-  crt::crt_carry_launch(g, im.w61, im.w31, im.x, im.carry, im.residual, true, s);
+  crt::crt_carry_launch_linked(g, im.w61, im.w31, im.x, im.carry, s);   // (im.carry: 16 bytes per run allocated, 3 words per 256 runs used)
   mark();
 }
 

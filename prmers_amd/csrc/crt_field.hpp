@@ -116,5 +116,7 @@ Geom make_geom(uint32_t p, size_t n, uint32_t odd, uint32_t a);   // crt_carry.h
 void crt_carry_launch(const Geom& g, const uint64_t* in61, const uint32_t* in31, uint64_t* digits, uint64_t* carry, uint64_t* residual,
                       bool fold_residual, hipStream_t s);
 
+void crt_carry_launch_linked(const Geom& g, const uint64_t* in61, const uint32_t* in31, uint64_t* digits, uint64_t* edge, hipStream_t s);
+
 }  // namespace crt
 }  // namespace mi355
