@@ -113,6 +113,19 @@ __device__ __forceinline__ F61::C cmul61(Lz61 x, F61::C w) {
   return {canon61(S), canon61(T)};
 }
 
+// Z/M31[i] product with both partial products of a component accumulated in one 64-bit multiply-add chain (a c + b (M31 - d) < 2^63)
+// and one reduction per component (canonical operands and result)
+__device__ __forceinline__ uint32_t red31_63(uint64_t x) {                       // x < 2^63
+  const uint32_t y = (uint32_t(x) & M31) + (uint32_t(x >> 31) & M31) + uint32_t(x >> 62);   // <= 2^32 - 1
+  const uint32_t z = (y & M31) + (y >> 31);                                       // <= M31 + 1
+  return min(z, z - M31);                                                         // unsigned wrap: z < M31 keeps z
+}
+template <bool CONJ>
+__device__ __forceinline__ F31::C cmul31(F31::C x, F31::C w) {
+  const uint32_t d = CONJ ? (w.im ^ M31) : w.im, n = CONJ ? w.im : (w.im ^ M31);  // M31 - d is the bit complement
+  return {red31_63(uint64_t(x.re) * w.re + uint64_t(x.im) * n), red31_63(uint64_t(x.re) * d + uint64_t(x.im) * w.re)};
+}
+
 // out[k] = sum_q in[q] w^(qk), w = omega_R (forward) or its conjugate (INV, unnormalised); natural order in and out
 template <class F, int R, bool INV>
 __device__ __forceinline__ void bfly(typename F::C (&x)[R]) {
@@ -152,12 +165,12 @@ __device__ __forceinline__ void step(const Planes& P, uint32_t tid, uint32_t log
     for (int q = 0; q < R; ++q) x[q] = Slot<F>::get(P, base + (uint32_t(q) << logSr));
     if (INV && logSr) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) x[k] = cmul<F>(x[k], cconj<F>(WL[(j * uint32_t(k)) << (logL - logS)]));
+      for (int k = 1; k < R; ++k) x[k] = cmul31<true>(x[k], WL[(j * uint32_t(k)) << (logL - logS)]);
     }
     bfly<F, R, INV>(x);
     if (!INV && logSr) {
 #pragma unroll
-      for (int k = 1; k < R; ++k) x[k] = cmul<F>(x[k], WL[(j * uint32_t(k)) << (logL - logS)]);
+      for (int k = 1; k < R; ++k) x[k] = cmul31<false>(x[k], WL[(j * uint32_t(k)) << (logL - logS)]);
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) Slot<F>::put(P, base + (uint32_t(q) << logSr), x[q]);
@@ -250,7 +263,7 @@ __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C
     if (INV) {   // conj(omega_h^(k1 i2)) from the two small tables (a gather from the full table costs two 128-byte lines a slot)
       const uint32_t tw = 2u * i * (col0 + c);
       a = cmul61<true>(Lz61{a.re, a.im}, T.lo61[tw & 1023]); a = cmul61<true>(Lz61{a.re, a.im}, T.hi61[tw >> 10]);
-      b = cmul<F31>(cmul<F31>(b, cconj<F31>(T.lo31[tw & 1023])), cconj<F31>(T.hi31[tw >> 10]));
+      b = cmul31<true>(cmul31<true>(b, T.lo31[tw & 1023]), T.hi31[tw >> 10]);
       slot = (c << logL) + pos_of_freq(i, logL);
     }
     Slot<F61>::put(P, slot, a); Slot<F31>::put(P, slot, b);
@@ -264,7 +277,7 @@ __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C
     if (!INV) {
       const uint32_t tw = 2u * i * (col0 + c);
       a = cmul61<false>(Lz61{a.re, a.im}, T.lo61[tw & 1023]); a = cmul61<false>(Lz61{a.re, a.im}, T.hi61[tw >> 10]);
-      b = cmul<F31>(cmul<F31>(b, T.lo31[tw & 1023]), T.hi31[tw >> 10]);
+      b = cmul31<false>(cmul31<false>(b, T.lo31[tw & 1023]), T.hi31[tw >> 10]);
     }
     const size_t addr = size_t(i) * H2 + col0 + c;
     z61[addr] = a; z31[addr] = b;
@@ -272,28 +285,71 @@ __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C
 }
 
 // ---- middle: rows k1 and H1 - k1 (work-group 0 of a grid row: rows 0 and H1 / 2, each its own partner) ----
+// The conjugate-symmetric untangle / square / re-tangle (crt_engine.hip: spectrum_sq, repack) per field: Z/M31[i] on the generic forms
+// with the fused product, Z/M61[i] on the lazy forms (sums of up to three canonical values, one fold before a product).
+struct Pw31 {
+  using C = F31::C;
+  static __device__ __forceinline__ C mul(C a, C w) { return cmul31<false>(a, w); }
+  static __device__ __forceinline__ C mulc(C a, C w) { return cmul31<true>(a, w); }
+  static __device__ __forceinline__ C spectrum(C zk, C zmk, C w) {
+    const C zc = cconj<F31>(zmk);
+    const C e = cadd<F31>(zk, zc), o = cdiv_i<F31>(csub<F31>(zk, zc));
+    const C x = chalf<F31>(cadd<F31>(e, mul(o, w)));
+    return mul(x, x);
+  }
+  static __device__ __forceinline__ C repack(C yk, C yhk, C w) {
+    const C yc = cconj<F31>(yhk);
+    const C e = cadd<F31>(yk, yc), d = mulc(csub<F31>(yk, yc), w);
+    return chalf<F31>(cadd<F31>(e, cmul_i<F31>(d)));
+  }
+};
+__device__ __forceinline__ uint64_t half61(uint64_t v) { return (v & 1) ? (v + M61) >> 1 : v >> 1; }   // v <= 3 M61 -> <= 2 M61
+struct Pw61 {
+  using C = F61::C;
+  static __device__ __forceinline__ C spectrum(C zk, C zmk, C w) {
+    // e = zk + conj(zmk), o = (zk - conj(zmk)) / i = (d.im, -d.re); all <= 2 M61
+    const Lz61 e{zk.re + zmk.re, zk.im + (K1 - zmk.im)};
+    const Lz61 o{zk.im + zmk.im, K2 - (zk.re + (K1 - zmk.re))};
+    const C t = cmul61<false>(Lz61{fold61(o.re), fold61(o.im)}, w);
+    const C x{canon61(half61(e.re + t.re)), canon61(half61(e.im + t.im))};
+    return cmul61<false>(Lz61{x.re, x.im}, x);
+  }
+  static __device__ __forceinline__ C repack(C yk, C yhk, C w) {
+    const Lz61 e{yk.re + yhk.re, yk.im + (K1 - yhk.im)};
+    const Lz61 df{fold61(yk.re + (K1 - yhk.re)), fold61(yk.im + yhk.im)};
+    const C d = cmul61<true>(df, w);
+    return {canon61(half61(e.re + (K1 - d.im))), canon61(half61(e.im + d.re))};   // (e + i d) / 2
+  }
+};
+template <class F> struct PwOf;
+template <> struct PwOf<F61> { using T = Pw61; };
+template <> struct PwOf<F31> { using T = Pw31; };
+
 template <class F>
 __device__ __forceinline__ void pointwise_pair(const Planes& P, uint32_t sa, uint32_t sb, typename F::C wa) {
   using C = typename F::C;
+  using PW = typename PwOf<F>::T;
   const C za = Slot<F>::get(P, sa), zb = Slot<F>::get(P, sb);
   const C wb = cneg<F>(cconj<F>(wa));                                   // omega_m^(h - k) = -conj(omega_m^k)
-  const C ya = spectrum_sq<F>(za, zb, wa), yb = spectrum_sq<F>(zb, za, wb);
-  Slot<F>::put(P, sa, repack<F>(ya, yb, wa));
-  Slot<F>::put(P, sb, repack<F>(yb, ya, wb));
+  const C ya = PW::spectrum(za, zb, wa), yb = PW::spectrum(zb, za, wb);
+  Slot<F>::put(P, sa, PW::repack(ya, yb, wa));
+  Slot<F>::put(P, sb, PW::repack(yb, ya, wb));
 }
 template <class F>
 __device__ __forceinline__ void pointwise_self(const Planes& P, uint32_t s, typename F::C w) {   // k = h / 2: its own partner
+  using PW = typename PwOf<F>::T;
   const typename F::C z = Slot<F>::get(P, s);
-  const typename F::C y = spectrum_sq<F>(z, z, w);
-  Slot<F>::put(P, s, repack<F>(y, y, w));
+  const typename F::C y = PW::spectrum(z, z, w);
+  Slot<F>::put(P, s, PW::repack(y, y, w));
 }
 template <class F>
 __device__ __forceinline__ void pointwise_zero(const Planes& P, uint32_t s) {                      // k = 0 with k = h folded in
   using C = typename F::C;
+  using PW = typename PwOf<F>::T;
   const C z = Slot<F>::get(P, s);
   const C one{1, 0}, mone{F::M - 1, 0};
-  const C y0 = spectrum_sq<F>(z, z, one), yh = spectrum_sq<F>(z, z, mone);
-  Slot<F>::put(P, s, repack<F>(y0, yh, one));
+  const C y0 = PW::spectrum(z, z, one), yh = PW::spectrum(z, z, mone);
+  Slot<F>::put(P, s, PW::repack(y0, yh, one));
 }
 
 __global__ void __launch_bounds__(256) k_mid_fast(Grid gr, FastTables T, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
@@ -317,12 +373,12 @@ __global__ void __launch_bounds__(256) k_mid_fast(Grid gr, FastTables T, F61::C*
     const uint32_t q = tid + 256u * it;                                 // 0 .. 1023
     if (b) {                                                            // (row a, k2 = q) <-> (row b, k2 = L - 1 - q)
       const uint32_t sa = pos_of_freq(q, logL), sb = L + pos_of_freq(L - 1 - q, logL);
-      pointwise_pair<F61>(P, sa, sb, cmul<F61>(ua61, T.v61[q]));
-      pointwise_pair<F31>(P, sa, sb, cmul<F31>(ua31, T.v31[q]));
+      pointwise_pair<F61>(P, sa, sb, cmul61<false>(Lz61{ua61.re, ua61.im}, T.v61[q]));
+      pointwise_pair<F31>(P, sa, sb, cmul31<false>(ua31, T.v31[q]));
     } else if (q < (L >> 1)) {                                          // row H1/2: k2 = q <-> L - 1 - q
       const uint32_t sa = L + pos_of_freq(q, logL), sb = L + pos_of_freq(L - 1 - q, logL);
-      pointwise_pair<F61>(P, sa, sb, cmul<F61>(ub61, T.v61[q]));
-      pointwise_pair<F31>(P, sa, sb, cmul<F31>(ub31, T.v31[q]));
+      pointwise_pair<F61>(P, sa, sb, cmul61<false>(Lz61{ub61.re, ub61.im}, T.v61[q]));
+      pointwise_pair<F31>(P, sa, sb, cmul31<false>(ub31, T.v31[q]));
     } else {                                                            // row 0: k2 = q' <-> L - q'
       const uint32_t qq = q - (L >> 1);
       if (qq == 0) {
