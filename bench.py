@@ -68,26 +68,26 @@ def bench_crt(args):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         raise SystemExit("--field crt is a single-GPU line")
     p = args.exponent or 205271257
-    eng = CrtEngine(p, args.odd, args.words)
+    eng = CrtEngine(p, args.odd, args.words, reg_count=1)
     n = eng.n
     j = np.arange(n + 1, dtype=np.uint64)
     ceil = (j * np.uint64(p) + np.uint64(n - 1)) // np.uint64(n)
     width = (ceil[1:] - ceil[:-1]).astype(np.uint64)
-    eng.set_digits(np.random.default_rng(1000).integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << width) - np.uint64(1)))
+    eng.set_digits(0, np.random.default_rng(1000).integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << width) - np.uint64(1)))
     t_start = time.perf_counter()
     while args.preheat_seconds > 0 and time.perf_counter() - t_start < args.preheat_seconds:
         for _ in range(50):
-            eng.square_mul(1)
+            eng.square_mul(0, 1)
         eng.sync()
     for _ in range(max(1, args.warmup)):
-        eng.square_mul(1)
+        eng.square_mul(0, 1)
     eng.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.square_mul(1)
+        eng.square_mul(0, 1)
     eng.sync(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    _, kern = eng.time_square_mul(min(args.steps, 32))
+    _, kern = eng.time_square_mul(0, min(args.steps, 32))
     ms = 1e3 * elapsed / args.steps
     dom = max(kern, key=kern.get)
     bytes_iter = eng.algorithmic_bytes()

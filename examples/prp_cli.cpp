@@ -103,6 +103,7 @@ int main(int argc, char** argv) {
             if (iter == 0) { iter = iter - 1; j = j + 1; }
             checkpass = 0;   // RunPrpOrLlMarin.cpp:391
             ++errors;
+            if (errors > 64) { std::fprintf(stderr, "Error: %llu failed Gerbicz-Li checks, giving up (hardware or checkpoint problem)\n", (unsigned long long)errors); return 1; }
             eng->copy(R0, R4); eng->copy(R1, R5);
           } else {
             std::printf("[Gerbicz Li] Check passed! iter=%llu\n", (unsigned long long)(iter + 1));
@@ -115,7 +116,7 @@ int main(int argc, char** argv) {
       if (proof && proof->should_checkpoint(uint32_t(iter + 1))) proof->save(uint32_t(iter + 1), residue_words(eng.get(), R0, p));
       if (!ckpt.empty() && backup && done % backup == 0) fmt::save_checkpoint(ckpt, *eng, p, ll, uint32_t(iter + 1), elapsed0);
     }
-    if (!ckpt.empty() && !complete) fmt::save_checkpoint(ckpt, *eng, p, ll, uint32_t(last_iter - (maxiters && done >= maxiters ? 1 : 0)), elapsed0);
+    if (!ckpt.empty() && !complete) fmt::save_checkpoint(ckpt, *eng, p, ll, uint32_t(last_iter), elapsed0);   // iterations completed = the next iteration index
     engine::digit d(eng.get(), R0);
     const bool prime = ll ? (d.equal_to(0) || d.equal_to_Mp()) : d.equal_to(9);
     std::printf("M%u %s: %s  res64(raw)=%016llX  gerbicz_errors=%llu  n=%zu\n", p, ll ? "LL" : "PRP-3",

@@ -114,33 +114,17 @@ MI355_ENGINE_API size_t mi355_engine_algorithmic_bytes(mi355_engine_handle handl
 MI355_ENGINE_API int mi355_crt_carry(uint32_t exponent, size_t transform_words, uint32_t odd_radix, uint32_t factor, const uint64_t* in61,
                                      const uint32_t* in31, uint64_t* digits_out, uint64_t* residual_out, size_t device, double* kernel_ms);
 
-/* ---- second field family: the resident squaring engine ----
-   x <- x^2 * factor mod 2^p - 1 over GF(M61^2) x GF(M31^2) with a prime-factor axis of radix odd_radix in {1, 3, 9}: what the
-   reference's Aevum plugin does behind the same EngineApi.h shapes (third_party/aevum/src/EngineApi.h:28-59; fft-middle.cl:663-720,
-   pfaunpack.cl:12-56, carry.cl:506-588; transform sizes README.md:907-926).  One residue per handle (the register file of the
-   Goldilocks engine is not mirrored yet): set / square_mul / sub / read-back, enough for an LL test or a PRP without Gerbicz checks.
-   transform_words = 0 picks the smallest admissible odd_radix * 2^k; plan_spec NULL or "h2=K" (rows of 2^K complex values, tests).
-   Errors: 0 / NULL with mi355_engine_last_error(), as everywhere in this header. */
-typedef void* mi355_crt_handle;
+/* ---- second field family: selected by the fft_spec ----
+   mi355_engine_create(exponent, registers, device, verbose, "crt[:odd][:words=N][:h2=K]", NULL) returns an engine that computes over
+   GF(M61^2) x GF(M31^2) with a prime-factor axis of radix odd in {1, 3, 9} (default 1): what the reference's Aevum plugin does behind
+   the same EngineApi.h shapes (third_party/aevum/src/EngineApi.h:28-59; fft-middle.cl:663-720, pfaunpack.cl:12-56, carry.cl:506-588;
+   transform sizes README.md:907-926, e.g. "crt:9" = the radix-9 family, "crt:3:words=6291456").  words = 0 / absent: the smallest
+   admissible odd * 2^k.  Served by that engine: the 19 core entry points (create ... equal), get_digits / set_digits (PLAIN u64 values
+   here: widths reach 39 bits), res64, time_square_mul (sub must be 0), kernel_count / kernel_name, algorithmic_bytes, describe; the
+   raw images, checkpoints and the fused register operations answer 0 with "not implemented for the crt field family". */
 MI355_ENGINE_API size_t mi355_crt_transform_size(uint32_t exponent, uint32_t odd_radix);
-MI355_ENGINE_API mi355_crt_handle mi355_crt_create(uint32_t exponent, uint32_t odd_radix, size_t transform_words, uint32_t device, const char* plan_spec);
-MI355_ENGINE_API void mi355_crt_destroy(mi355_crt_handle handle);
-MI355_ENGINE_API size_t mi355_crt_size(mi355_crt_handle handle);
-MI355_ENGINE_API int mi355_crt_describe(mi355_crt_handle handle, char* output, size_t output_size);
-MI355_ENGINE_API int mi355_crt_sync(mi355_crt_handle handle);
-MI355_ENGINE_API int mi355_crt_set_u32(mi355_crt_handle handle, uint32_t value);
-MI355_ENGINE_API int mi355_crt_square_mul(mi355_crt_handle handle, uint32_t factor);
-MI355_ENGINE_API int mi355_crt_sub_u32(mi355_crt_handle handle, uint32_t value);
-/* digits in base 2^width_j, logical order, plain u64 values (widths reach 39 bits); canonical != 0: after the strong carry */
-MI355_ENGINE_API int mi355_crt_get_digits(mi355_crt_handle handle, uint64_t* digits, size_t count, int canonical);
-MI355_ENGINE_API int mi355_crt_set_digits(mi355_crt_handle handle, const uint64_t* digits, size_t count);
-/* canonical little-endian 32-bit words, 2^p - 1 reads as 0 (EngineApi.cpp:210-218) */
-MI355_ENGINE_API int mi355_crt_get_words(mi355_crt_handle handle, uint32_t* words, size_t count);
-MI355_ENGINE_API int mi355_crt_res64(mi355_crt_handle handle, uint64_t* out);
-MI355_ENGINE_API int mi355_crt_time_square_mul(mi355_crt_handle handle, uint32_t factor, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count);
-MI355_ENGINE_API size_t mi355_crt_kernel_count(void);
-MI355_ENGINE_API const char* mi355_crt_kernel_name(size_t k);
-MI355_ENGINE_API size_t mi355_crt_algorithmic_bytes(mi355_crt_handle handle);
+/* plan text of a live engine: "marin-hip:n=...:m1=...:m2=...:c=..." or "crt-hip:n=...:odd=...:m=...:h1=...:h2=...:radix8|generic" */
+MI355_ENGINE_API int mi355_engine_describe(mi355_engine_handle handle, char* output, size_t output_size);
 
 #ifdef __cplusplus
 }

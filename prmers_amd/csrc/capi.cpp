@@ -2,6 +2,7 @@
 // reports through last_error, as the reference's plugin does (third_party/aevum/src/EngineApi.cpp:447-517).
 #include "../../include/mi355_engine.h"
 
+#include <cctype>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -31,14 +32,43 @@ int guarded(F&& f) {
   return 0;
 }
 
-mi355::CrtEngine* crt(mi355_crt_handle h) {
+// One handle type for both field families: the Goldilocks engine (engine.hip) or, when the fft_spec starts with "crt", the
+// GF(M61^2) x GF(M31^2) engine with the prime-factor axis (crt_engine.hip) -- the reference selects its backends the same way, by the
+// spec string handed to its plugin (third_party/aevum/src/EngineApi.cpp:75-120, `-fft`).
+struct Handle {
+  mi355::Engine* g = nullptr;
+  mi355::CrtEngine* c = nullptr;
+  ~Handle() { delete g; delete c; }
+};
+Handle* hnd(mi355_engine_handle h) {
   if (!h) throw std::runtime_error("null engine handle");
-  return static_cast<mi355::CrtEngine*>(h);
+  return static_cast<Handle*>(h);
 }
-
 mi355::Engine* eng(mi355_engine_handle h) {
-  if (!h) throw std::runtime_error("null engine handle");
-  return static_cast<mi355::Engine*>(h);
+  Handle* H = hnd(h);
+  if (!H->g) throw std::runtime_error("this operation is not implemented for the crt field family");
+  return H->g;
+}
+mi355::CrtEngine* crt(mi355_engine_handle h) { return hnd(h)->c; }   // nullptr for a Goldilocks handle
+
+// "crt", "crt:9", "crt:3:words=6291456", "crt:9:h2=5" ...
+struct CrtSpec { uint32_t odd = 1; size_t words = 0; std::string rest; };
+bool parse_crt_spec(const char* spec, CrtSpec& out) {
+  if (!spec || std::strncmp(spec, "crt", 3) != 0 || (spec[3] != 0 && spec[3] != ':')) return false;
+  std::string s = spec[3] ? spec + 4 : "";
+  size_t pos = 0;
+  bool first = true;
+  while (pos <= s.size() && !s.empty()) {
+    const size_t e = s.find(':', pos);
+    const std::string tok = s.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+    if (first && !tok.empty() && std::isdigit(static_cast<unsigned char>(tok[0]))) out.odd = uint32_t(std::stoul(tok));
+    else if (tok.rfind("words=", 0) == 0) out.words = std::stoull(tok.substr(6));
+    else if (!tok.empty()) out.rest = tok;
+    first = false;
+    if (e == std::string::npos) break;
+    pos = e + 1;
+  }
+  return true;
 }
 
 }  // namespace
@@ -51,8 +81,15 @@ const char* mi355_engine_last_error(void) { return g_last_error.c_str(); }
 int mi355_engine_resolve_fft(uint32_t exponent, const char* fft_spec, char* output, size_t output_size) {
   return guarded([&] {
     if (!output || output_size == 0) throw std::runtime_error("resolve_fft: no output buffer");
-    const mi355::Plan pl = mi355::make_plan(exponent, fft_spec, false);
-    const std::string s = pl.describe();
+    std::string s;
+    CrtSpec cs;
+    if (parse_crt_spec(fft_spec, cs)) {
+      const size_t n = cs.words ? cs.words : mi355::crt_transform_size(exponent, cs.odd);
+      if (!n) throw std::runtime_error("resolve_fft: no admissible crt transform size");
+      s = "crt-hip:n=" + std::to_string(n) + ":odd=" + std::to_string(cs.odd);
+    } else {
+      s = mi355::make_plan(exponent, fft_spec, false).describe();
+    }
     if (s.size() + 1 > output_size) throw std::runtime_error("resolve_fft: output buffer too small");
     std::memcpy(output, s.c_str(), s.size() + 1);
   });
@@ -60,35 +97,43 @@ int mi355_engine_resolve_fft(uint32_t exponent, const char* fft_spec, char* outp
 
 mi355_engine_handle mi355_engine_create(uint32_t exponent, size_t register_count, uint32_t device, int verbose,
                                         const char* fft_spec, const char* /*tune_dir*/) {
-  mi355::Engine* e = nullptr;
-  if (!guarded([&] { e = new mi355::Engine(exponent, register_count, int(device), verbose != 0, fft_spec); })) return nullptr;
-  return e;
+  Handle* H = nullptr;
+  if (!guarded([&] {
+        H = new Handle;
+        CrtSpec cs;
+        if (parse_crt_spec(fft_spec, cs)) H->c = new mi355::CrtEngine(exponent, register_count, cs.odd, cs.words, int(device), cs.rest.empty() ? nullptr : cs.rest.c_str());
+        else H->g = new mi355::Engine(exponent, register_count, int(device), verbose != 0, fft_spec);
+      })) {
+    delete H;
+    return nullptr;
+  }
+  return H;
 }
 
 void mi355_engine_destroy(mi355_engine_handle h) {
-  guarded([&] { delete static_cast<mi355::Engine*>(h); });
+  guarded([&] { delete static_cast<Handle*>(h); });
 }
 
-size_t mi355_engine_transform_size(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->n(); }); return r; }
-size_t mi355_engine_word_count(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->word_count(); }); return r; }
-int mi355_engine_sync(mi355_engine_handle h) { return guarded([&] { eng(h)->sync(); }); }
+size_t mi355_engine_transform_size(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = (crt(h) ? crt(h)->size() : eng(h)->n()); }); return r; }
+size_t mi355_engine_word_count(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = (crt(h) ? (size_t(crt(h)->exponent()) + 31) / 32 : eng(h)->word_count()); }); return r; }
+int mi355_engine_sync(mi355_engine_handle h) { return guarded([&] { if (crt(h)) crt(h)->sync(); else eng(h)->sync(); }); }
 
-int mi355_engine_set_u32(mi355_engine_handle h, size_t dst, uint32_t v) { return guarded([&] { eng(h)->set_u32(dst, v); }); }
+int mi355_engine_set_u32(mi355_engine_handle h, size_t dst, uint32_t v) { return guarded([&] { if (crt(h)) crt(h)->set_u32(dst, v); else eng(h)->set_u32(dst, v); }); }
 int mi355_engine_set_words(mi355_engine_handle h, size_t dst, const uint32_t* w, size_t count) {
-  return guarded([&] { if (!w) throw std::runtime_error("set_words: null buffer"); eng(h)->set_words(dst, w, count); });
+  return guarded([&] { if (!w) throw std::runtime_error("set_words: null buffer"); if (crt(h)) crt(h)->set_words(dst, w, count); else eng(h)->set_words(dst, w, count); });
 }
 int mi355_engine_get_words(mi355_engine_handle h, size_t src, uint32_t* w, size_t count) {
-  return guarded([&] { if (!w) throw std::runtime_error("get_words: null buffer"); eng(h)->get_words(src, w, count); });
+  return guarded([&] { if (!w) throw std::runtime_error("get_words: null buffer"); if (crt(h)) crt(h)->get_words(src, w, count); else eng(h)->get_words(src, w, count); });
 }
-int mi355_engine_copy(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { eng(h)->copy(dst, src); }); }
-int mi355_engine_prepare(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { eng(h)->prepare(dst, src); }); }
-int mi355_engine_square_mul(mi355_engine_handle h, size_t r, uint32_t f) { return guarded([&] { eng(h)->square_mul(r, f); }); }
-int mi355_engine_mul(mi355_engine_handle h, size_t dst, size_t src, uint32_t f) { return guarded([&] { eng(h)->mul(dst, src, f); }); }
-int mi355_engine_add(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { eng(h)->add(dst, src); }); }
-int mi355_engine_sub_reg(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { eng(h)->sub_reg(dst, src); }); }
-int mi355_engine_sub_u32(mi355_engine_handle h, size_t dst, uint32_t v) { return guarded([&] { eng(h)->sub_u32(dst, v); }); }
+int mi355_engine_copy(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { if (crt(h)) crt(h)->copy(dst, src); else eng(h)->copy(dst, src); }); }
+int mi355_engine_prepare(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { if (crt(h)) crt(h)->set_multiplicand(dst, src); else eng(h)->prepare(dst, src); }); }
+int mi355_engine_square_mul(mi355_engine_handle h, size_t r, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->square_mul(r, f); else eng(h)->square_mul(r, f); }); }
+int mi355_engine_mul(mi355_engine_handle h, size_t dst, size_t src, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->mul(dst, src, f); else eng(h)->mul(dst, src, f); }); }
+int mi355_engine_add(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { if (crt(h)) crt(h)->add(dst, src); else eng(h)->add(dst, src); }); }
+int mi355_engine_sub_reg(mi355_engine_handle h, size_t dst, size_t src) { return guarded([&] { if (crt(h)) crt(h)->sub_reg(dst, src); else eng(h)->sub_reg(dst, src); }); }
+int mi355_engine_sub_u32(mi355_engine_handle h, size_t dst, uint32_t v) { return guarded([&] { if (crt(h)) crt(h)->sub_u32(dst, v); else eng(h)->sub_u32(dst, v); }); }
 int mi355_engine_equal(mi355_engine_handle h, size_t lhs, size_t rhs, int* out) {
-  return guarded([&] { if (!out) throw std::runtime_error("equal: null output"); *out = eng(h)->equal(lhs, rhs) ? 1 : 0; });
+  return guarded([&] { if (!out) throw std::runtime_error("equal: null output"); *out = (crt(h) ? crt(h)->equal(lhs, rhs) : eng(h)->equal(lhs, rhs)) ? 1 : 0; });
 }
 
 int mi355_engine_addsub(mi355_engine_handle h, size_t so, size_t dout, size_t a, size_t b) { return guarded([&] { eng(h)->addsub(so, dout, a, b); }); }
@@ -100,13 +145,13 @@ int mi355_engine_square_mul_copy(mi355_engine_handle h, size_t src, size_t cp, u
 int mi355_engine_mul_copy(mi355_engine_handle h, size_t dst, size_t src, size_t cp, uint32_t f) { return guarded([&] { eng(h)->mul_copy(dst, src, cp, f); }); }
 
 int mi355_engine_get_digits(mi355_engine_handle h, size_t src, uint64_t* d, size_t count) {
-  return guarded([&] { if (!d) throw std::runtime_error("get_digits: null buffer"); eng(h)->get_digits(src, d, count); });
+  return guarded([&] { if (!d) throw std::runtime_error("get_digits: null buffer"); if (crt(h)) crt(h)->get_digits(src, d, count, true); else eng(h)->get_digits(src, d, count); });
 }
 int mi355_engine_set_digits(mi355_engine_handle h, size_t dst, const uint64_t* d, size_t count) {
-  return guarded([&] { if (!d) throw std::runtime_error("set_digits: null buffer"); eng(h)->set_digits(dst, d, count); });
+  return guarded([&] { if (!d) throw std::runtime_error("set_digits: null buffer"); if (crt(h)) crt(h)->set_digits(dst, d, count); else eng(h)->set_digits(dst, d, count); });
 }
 int mi355_engine_res64(mi355_engine_handle h, size_t src, uint64_t* out) {
-  return guarded([&] { if (!out) throw std::runtime_error("res64: null output"); *out = eng(h)->res64(src); });
+  return guarded([&] { if (!out) throw std::runtime_error("res64: null output"); *out = crt(h) ? crt(h)->res64(src) : eng(h)->res64(src); });
 }
 size_t mi355_engine_register_data_size(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->register_data_size(); }); return r; }
 int mi355_engine_get_data(mi355_engine_handle h, size_t src, void* data, size_t size) {
@@ -125,10 +170,19 @@ int mi355_engine_set_checkpoint(mi355_engine_handle h, const void* data, size_t 
 
 int mi355_engine_time_square_mul(mi355_engine_handle h, size_t reg, uint32_t factor, uint32_t sub, size_t iters,
                                  double* total_ms, double* kernel_ms, size_t kernel_count) {
-  return guarded([&] { eng(h)->time_square_mul(reg, factor, sub, iters, total_ms, kernel_ms, kernel_count); });
+  return guarded([&] { if (crt(h)) { if (sub) throw std::runtime_error("time_square_mul: no deferred subtraction on the crt family"); crt(h)->time_square_mul(reg, factor, iters, total_ms, kernel_ms, kernel_count); } else eng(h)->time_square_mul(reg, factor, sub, iters, total_ms, kernel_ms, kernel_count); });
 }
-size_t mi355_engine_kernel_count(mi355_engine_handle) { return mi355::Engine::kKernels; }
-const char* mi355_engine_kernel_name(mi355_engine_handle, size_t k) { return mi355::Engine::kernel_name(k); }
+size_t mi355_engine_kernel_count(mi355_engine_handle h) { return (h && static_cast<Handle*>(h)->c) ? size_t(mi355::CrtEngine::kKernels) : size_t(mi355::Engine::kKernels); }
+const char* mi355_engine_kernel_name(mi355_engine_handle h, size_t k) {
+  return (h && static_cast<Handle*>(h)->c) ? mi355::CrtEngine::kernel_name(k) : mi355::Engine::kernel_name(k);
+}
+int mi355_engine_describe(mi355_engine_handle h, char* output, size_t output_size) {
+  return guarded([&] {
+    const std::string s = crt(h) ? crt(h)->describe() : eng(h)->plan().describe();
+    if (!output || s.size() + 1 > output_size) throw std::runtime_error("describe: output buffer too small");
+    std::memcpy(output, s.c_str(), s.size() + 1);
+  });
+}
 int mi355_engine_selftest(size_t device) { return guarded([&] { mi355::selftest_primitives(int(device)); }); }
 int mi355_crt_carry(uint32_t exponent, size_t words, uint32_t odd, uint32_t factor, const uint64_t* in61, const uint32_t* in31, uint64_t* digits_out,
                     uint64_t* residual_out, size_t device, double* kernel_ms) {
@@ -138,40 +192,6 @@ int mi355_crt_carry(uint32_t exponent, size_t words, uint32_t odd, uint32_t fact
   });
 }
 size_t mi355_crt_transform_size(uint32_t exponent, uint32_t odd) { size_t r = 0; guarded([&] { r = mi355::crt_transform_size(exponent, odd); }); return r; }
-mi355_crt_handle mi355_crt_create(uint32_t exponent, uint32_t odd, size_t words, uint32_t device, const char* spec) {
-  mi355::CrtEngine* e = nullptr;
-  if (!guarded([&] { e = new mi355::CrtEngine(exponent, odd, words, int(device), spec); })) return nullptr;
-  return e;
-}
-void mi355_crt_destroy(mi355_crt_handle h) { guarded([&] { delete static_cast<mi355::CrtEngine*>(h); }); }
-size_t mi355_crt_size(mi355_crt_handle h) { size_t r = 0; guarded([&] { r = crt(h)->size(); }); return r; }
-int mi355_crt_describe(mi355_crt_handle h, char* output, size_t output_size) {
-  return guarded([&] {
-    const std::string s = crt(h)->describe();
-    if (!output || s.size() + 1 > output_size) throw std::runtime_error("describe: output buffer too small");
-    std::memcpy(output, s.c_str(), s.size() + 1);
-  });
-}
-int mi355_crt_sync(mi355_crt_handle h) { return guarded([&] { crt(h)->sync(); }); }
-int mi355_crt_set_u32(mi355_crt_handle h, uint32_t v) { return guarded([&] { crt(h)->set_u32(v); }); }
-int mi355_crt_square_mul(mi355_crt_handle h, uint32_t a) { return guarded([&] { crt(h)->square_mul(a); }); }
-int mi355_crt_sub_u32(mi355_crt_handle h, uint32_t v) { return guarded([&] { crt(h)->sub_u32(v); }); }
-int mi355_crt_get_digits(mi355_crt_handle h, uint64_t* d, size_t count, int canonical) {
-  return guarded([&] { if (!d) throw std::runtime_error("get_digits: null buffer"); crt(h)->get_digits(d, count, canonical != 0); });
-}
-int mi355_crt_set_digits(mi355_crt_handle h, const uint64_t* d, size_t count) {
-  return guarded([&] { if (!d) throw std::runtime_error("set_digits: null buffer"); crt(h)->set_digits(d, count); });
-}
-int mi355_crt_get_words(mi355_crt_handle h, uint32_t* w, size_t count) {
-  return guarded([&] { if (!w) throw std::runtime_error("get_words: null buffer"); crt(h)->get_words(w, count); });
-}
-int mi355_crt_res64(mi355_crt_handle h, uint64_t* out) { return guarded([&] { if (!out) throw std::runtime_error("res64: null output"); *out = crt(h)->res64(); }); }
-int mi355_crt_time_square_mul(mi355_crt_handle h, uint32_t a, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count) {
-  return guarded([&] { crt(h)->time_square_mul(a, iters, total_ms, kernel_ms, kernel_count); });
-}
-size_t mi355_crt_kernel_count(void) { return mi355::CrtEngine::kKernels; }
-const char* mi355_crt_kernel_name(size_t k) { return mi355::CrtEngine::kernel_name(k); }
-size_t mi355_crt_algorithmic_bytes(mi355_crt_handle h) { size_t r = 0; guarded([&] { r = crt(h)->algorithmic_bytes(); }); return r; }
-size_t mi355_engine_algorithmic_bytes(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->algorithmic_bytes(); }); return r; }
+size_t mi355_engine_algorithmic_bytes(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = crt(h) ? crt(h)->algorithmic_bytes() : eng(h)->algorithmic_bytes(); }); return r; }
 
 }  // extern "C"

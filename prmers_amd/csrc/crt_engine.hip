@@ -232,23 +232,35 @@ __device__ __forceinline__ typename F::C repack(typename F::C yk, typename F::C 
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) k_pointwise(Grid gr, typename F::C* __restrict__ Z, const typename F::C* __restrict__ U) {
+__device__ __forceinline__ typename F::C spectrum_lin(typename F::C zk, typename F::C zmk, typename F::C w) {
+  const typename F::C zc = cconj<F>(zmk);
+  const typename F::C e = cadd<F>(zk, zc), o = cdiv_i<F>(csub<F>(zk, zc));
+  return chalf<F>(cadd<F>(e, cmul<F>(w, o)));
+}
+// I == nullptr: square; otherwise multiply by the packed spectrum I (same slot order)
+template <class F>
+__global__ void __launch_bounds__(256) k_pointwise(Grid gr, typename F::C* __restrict__ Z, const typename F::C* __restrict__ U, const typename F::C* __restrict__ I) {
   using C = typename F::C;
   const uint32_t per_row = (gr.h >> 1) + 1;
   const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= per_row * gr.odd) return;
   const uint32_t row = idx / per_row, k = idx - row * per_row;
   C* z = Z + size_t(row) * gr.h;
+  const C* im = I ? I + size_t(row) * gr.h : nullptr;
   const uint32_t h = gr.h;
+  auto prod = [&](C zk, C zmk, C ik, C imk, C w) {
+    const C x = spectrum_lin<F>(zk, zmk, w);
+    return im ? cmul<F>(x, spectrum_lin<F>(ik, imk, w)) : csqr<F>(x);
+  };
   if (k == 0) {
-    const C z0 = z[0];
-    const C y0 = spectrum_sq<F>(z0, z0, U[0]);            // X_0
-    const C yh = spectrum_sq<F>(z0, z0, U[h]);            // X_h (W^h = -1)
+    const C z0 = z[0], i0 = im ? im[0] : z0;
+    const C y0 = prod(z0, z0, i0, i0, U[0]);              // X_0
+    const C yh = prod(z0, z0, i0, i0, U[h]);              // X_h (W^h = -1)
     z[0] = repack<F>(y0, yh, U[0]);
     if (h >= 2) {   // the self-paired middle slot
       const uint32_t sm = slot_of(gr, h >> 1);
-      const C zm = z[sm];
-      const C ym = spectrum_sq<F>(zm, zm, U[h >> 1]);
+      const C zm = z[sm], imm = im ? im[sm] : zm;
+      const C ym = prod(zm, zm, imm, imm, U[h >> 1]);
       z[sm] = repack<F>(ym, ym, U[h >> 1]);
     }
     return;
@@ -256,10 +268,17 @@ __global__ void __launch_bounds__(256) k_pointwise(Grid gr, typename F::C* __res
   if (2 * k >= h) return;   // k = h / 2 was handled with k = 0
   const uint32_t sa = slot_of(gr, k), sb = slot_of(gr, h - k);
   const C za = z[sa], zb = z[sb];
+  const C ia = im ? im[sa] : za, ib = im ? im[sb] : zb;
   const C wa = U[k], wb = U[h - k];
-  const C ya = spectrum_sq<F>(za, zb, wa), yb = spectrum_sq<F>(zb, za, wb);
+  const C ya = prod(za, zb, ia, ib, wa), yb = prod(zb, za, ib, ia, wb);
   z[sa] = repack<F>(ya, yb, wa);
   z[sb] = repack<F>(yb, ya, wb);
+}
+
+// dst[j] += src[j]: digit-wise sum of two weakly carried residues (one more bit per digit; the next squaring's carry sweep absorbs it)
+__global__ void __launch_bounds__(256) k_add_digits(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t n) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) dst[j] += src[j];
 }
 
 }  // namespace crt
@@ -366,7 +385,13 @@ struct CrtEngine::Impl {
   crt::Grid gr;
   int device = 0;
   hipStream_t stream = nullptr;
-  uint64_t* x = nullptr;          // [n] digits, logical order, weakly carried
+  struct Register {
+    uint64_t* x = nullptr;        // [n] digits, logical order, weakly carried
+    F61::C* i61 = nullptr;        // packed spectrum of a multiplicand (set_multiplicand), allocated on first use
+    F31::C* i31 = nullptr;
+    bool image = false;           // holds a multiplicand image instead of digits
+  };
+  std::vector<Register> regs;
   F61::C *Z61 = nullptr, *U61 = nullptr;
   F31::C *Z31 = nullptr, *U31 = nullptr;
   uint64_t *w61 = nullptr, *carry = nullptr, *residual = nullptr;
@@ -383,12 +408,13 @@ const char* CrtEngine::kernel_name(size_t k) {
   return k < kKernels ? names[k] : "";
 }
 
-CrtEngine::CrtEngine(uint32_t p, uint32_t odd, size_t n_forced, int device, const char* spec) : im_(new Impl) {
+CrtEngine::CrtEngine(uint32_t p, size_t reg_count, uint32_t odd, size_t n_forced, int device, const char* spec) : im_(new Impl) {
   Impl& im = *im_;
   try {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw std::runtime_error("no HIP device available: the MI355X engine has no CPU fallback");
     if (odd != 1 && odd != 3 && odd != 9) throw std::runtime_error("crt engine: odd radix must be 1, 3 or 9");
+    if (reg_count == 0 || reg_count > 64) throw std::runtime_error("crt engine: register count must be 1 .. 64");
     const size_t n = n_forced ? n_forced : crt_transform_size(p, odd);
     if (!n) throw std::runtime_error("crt engine: no admissible transform size for this exponent");
     if (std::log2(double(n)) + 2.0 * (double(p) / double(n) + 1.0) >= 92.0) throw std::runtime_error("crt engine: transform too small for this exponent");
@@ -427,12 +453,12 @@ CrtEngine::CrtEngine(uint32_t p, uint32_t odd, size_t n_forced, int device, cons
     chk(hipStreamCreateWithFlags(&im.stream, hipStreamNonBlocking), "stream");
     for (auto& e : im.ev) chk(hipEventCreate(&e), "event");
     const size_t h = gr.h, nruns = (n + crt::kRun - 1) / crt::kRun;
-    chk(hipMalloc(reinterpret_cast<void**>(&im.x), n * 8), "hipMalloc");
+    im.regs.resize(reg_count);
+    for (auto& r : im.regs) { chk(hipMalloc(reinterpret_cast<void**>(&r.x), n * 8), "hipMalloc"); chk(hipMemset(r.x, 0, n * 8), "memset"); }
     chk(hipMalloc(reinterpret_cast<void**>(&im.Z61), size_t(odd) * h * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.Z31), size_t(odd) * h * 8), "hipMalloc");
     chk(hipMalloc(reinterpret_cast<void**>(&im.U61), (h + 1) * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.U31), (h + 1) * 8), "hipMalloc");
     chk(hipMalloc(reinterpret_cast<void**>(&im.w61), n * 8), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.w31), n * 4), "hipMalloc");
     chk(hipMalloc(reinterpret_cast<void**>(&im.carry), nruns * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.residual), nruns * 8), "hipMalloc");
-    chk(hipMemset(im.x, 0, n * 8), "memset");
     // omega_m^k, k <= h
     {
       std::vector<F61::C> u61(h + 1); std::vector<F31::C> u31(h + 1);
@@ -478,7 +504,8 @@ void CrtEngine::release() {
   Impl& im = *im_;
   (void)hipSetDevice(im.device);
   if (im.stream) (void)hipStreamSynchronize(im.stream);
-  for (void* q : {static_cast<void*>(im.x), static_cast<void*>(im.Z61), static_cast<void*>(im.Z31), static_cast<void*>(im.U61), static_cast<void*>(im.U31),
+  for (auto& r : im.regs) for (void* q : {static_cast<void*>(r.x), static_cast<void*>(r.i61), static_cast<void*>(r.i31)}) if (q) (void)hipFree(q);
+  for (void* q : {static_cast<void*>(im.Z61), static_cast<void*>(im.Z31), static_cast<void*>(im.U61), static_cast<void*>(im.U31),
                   static_cast<void*>(im.w61), static_cast<void*>(im.w31), static_cast<void*>(im.carry), static_cast<void*>(im.residual),
                   static_cast<void*>(im.W1_61), static_cast<void*>(im.W2_61), static_cast<void*>(im.V61), static_cast<void*>(im.W1_31),
                   static_cast<void*>(im.W2_31), static_cast<void*>(im.V31), static_cast<void*>(im.LO61), static_cast<void*>(im.HI61),
@@ -526,19 +553,25 @@ static void launch_rows(const crt::Grid& gr, typename F::C* Z, const typename F:
   }
 }
 
-void CrtEngine::launch_square(uint32_t a, bool timed) {
+// forward transform of register `reg` into the work arrays Z (front + forward columns; the rows are part of the next stage), then
+//   mode 0: square, inverse, carry sweep back into `reg` (x a)
+//   mode 1: rows forward only -> the packed spectrum becomes the image of register `dst` (set_multiplicand)
+//   mode 2: multiply by the image of register `src`, inverse, carry sweep back into `reg` (x a)
+void CrtEngine::launch_transform(size_t reg, int mode, size_t other, uint32_t a, bool timed) {
   Impl& im = *im_;
   const crt::Grid& gr = im.gr;
   crt::Geom g = im.g; g.a = a;
   hipStream_t s = im.stream;
   const dim3 b256(256), gslots((gr.h + 255) / 256);
+  uint64_t* x = im.regs[reg].x;
+  F61::C* i61 = mode ? im.regs[other].i61 : nullptr; F31::C* i31 = mode ? im.regs[other].i31 : nullptr;
   int e = 0;
   auto mark = [&] { if (timed) chk(hipEventRecord(im.ev[e++], s), "event"); };
   mark();
   switch (gr.odd) {
-    case 1: hipLaunchKernelGGL((crt::k_front<1>), gslots, b256, 0, s, g, gr, im.x, im.Z61, im.Z31); break;
-    case 3: hipLaunchKernelGGL((crt::k_front<3>), gslots, b256, 0, s, g, gr, im.x, im.Z61, im.Z31); break;
-    default: hipLaunchKernelGGL((crt::k_front<9>), gslots, b256, 0, s, g, gr, im.x, im.Z61, im.Z31); break;
+    case 1: hipLaunchKernelGGL((crt::k_front<1>), gslots, b256, 0, s, g, gr, x, im.Z61, im.Z31); break;
+    case 3: hipLaunchKernelGGL((crt::k_front<3>), gslots, b256, 0, s, g, gr, x, im.Z61, im.Z31); break;
+    default: hipLaunchKernelGGL((crt::k_front<9>), gslots, b256, 0, s, g, gr, x, im.Z61, im.Z31); break;
   }
   mark();
   if (im.fast) {
@@ -546,7 +579,9 @@ void CrtEngine::launch_square(uint32_t a, bool timed) {
     const uint32_t CA = crt::kFastSlots >> gr.logH1, gcols = gr.odd * ((1u << gr.logH2) / CA), gmid = gr.odd * (1u << gr.logH1) / 2;
     hipLaunchKernelGGL((crt::k_cols_fast<false>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
     mark();
-    hipLaunchKernelGGL(crt::k_mid_fast, dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    if (mode == 0) hipLaunchKernelGGL((crt::k_mid_fast<0>), dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31, i61, i31);
+    else if (mode == 1) { hipLaunchKernelGGL((crt::k_mid_fast<1>), dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31, i61, i31); return; }
+    else hipLaunchKernelGGL((crt::k_mid_fast<2>), dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31, i61, i31);
     mark();
     hipLaunchKernelGGL((crt::k_cols_fast<true>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
     mark();   // slots: k_rows_fwd = forward columns, k_pointwise = the fused row kernel, k_rows_inv = inverse columns
@@ -554,9 +589,14 @@ void CrtEngine::launch_square(uint32_t a, bool timed) {
     launch_rows<F61>(gr, im.Z61, im.U61, false, s);
     launch_rows<F31>(gr, im.Z31, im.U31, false, s);
     mark();
+    if (mode == 1) {
+      chk(hipMemcpyAsync(i61, im.Z61, size_t(gr.odd) * gr.h * 16, hipMemcpyDeviceToDevice, s), "copy");
+      chk(hipMemcpyAsync(i31, im.Z31, size_t(gr.odd) * gr.h * 8, hipMemcpyDeviceToDevice, s), "copy");
+      return;
+    }
     const uint32_t pw = ((gr.h >> 1) + 1) * gr.odd;
-    hipLaunchKernelGGL((crt::k_pointwise<F61>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z61, im.U61);
-    hipLaunchKernelGGL((crt::k_pointwise<F31>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z31, im.U31);
+    hipLaunchKernelGGL((crt::k_pointwise<F61>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z61, im.U61, static_cast<const F61::C*>(i61));
+    hipLaunchKernelGGL((crt::k_pointwise<F31>), dim3((pw + 255) / 256), b256, 0, s, gr, im.Z31, im.U31, static_cast<const F31::C*>(i31));
     mark();
     launch_rows<F61>(gr, im.Z61, im.U61, true, s);
     launch_rows<F31>(gr, im.Z31, im.U31, true, s);
@@ -568,43 +608,122 @@ void CrtEngine::launch_square(uint32_t a, bool timed) {
     default: hipLaunchKernelGGL((crt::k_back<9>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;
   }
   mark();
-  crt::crt_carry_launch_linked(g, im.w61, im.w31, im.x, im.carry, s);   // (im.carry: 16 bytes per run allocated, 3 words per 256 runs used)
+  crt::crt_carry_launch_linked(g, im.w61, im.w31, x, im.carry, s);   // (im.carry: 16 bytes per run allocated, 3 words per 256 runs used)
   mark();
 }
 
-void CrtEngine::square_mul(uint32_t a) {
+size_t CrtEngine::reg_count() const { return im_->regs.size(); }
+
+void CrtEngine::check_digits(size_t reg, const char* what) const {
+  if (reg >= im_->regs.size()) throw std::runtime_error(std::string(what) + ": register index out of range");
+  if (im_->regs[reg].image) throw std::runtime_error(std::string(what) + ": register holds a multiplicand image, not a residue");
+}
+
+void CrtEngine::square_mul(size_t reg, uint32_t a) {
+  check_digits(reg, "square_mul");
   if (a == 0) throw std::runtime_error("square_mul: factor must be >= 1");
   chk(hipSetDevice(im_->device), "hipSetDevice");
-  launch_square(a, false);
+  launch_transform(reg, 0, 0, a, false);
 }
 
-void CrtEngine::set_u32(uint32_t a) {
+// dst <- the transformed image of src (engine::set_multiplicand, engine.h:53); dst may be src
+void CrtEngine::set_multiplicand(size_t dst, size_t src) {
   Impl& im = *im_;
+  check_digits(src, "set_multiplicand");
+  if (dst >= im.regs.size()) throw std::runtime_error("set_multiplicand: register index out of range");
   chk(hipSetDevice(im.device), "hipSetDevice");
-  chk(hipMemsetAsync(im.x, 0, size_t(im.g.n) * 8, im.stream), "memset");
-  if (a) hipLaunchKernelGGL(crt::k_set_small, dim3(1), dim3(1), 0, im.stream, im.g, im.x, a);
-}
-void CrtEngine::sub_u32(uint32_t a) {
-  Impl& im = *im_;
-  chk(hipSetDevice(im.device), "hipSetDevice");
-  if (a) hipLaunchKernelGGL(crt::k_sub_small, dim3(1), dim3(1), 0, im.stream, im.g, im.x, a);
+  Impl::Register& d = im.regs[dst];
+  if (!d.i61) {
+    chk(hipMalloc(reinterpret_cast<void**>(&d.i61), size_t(im.gr.odd) * im.gr.h * 16), "hipMalloc");
+    chk(hipMalloc(reinterpret_cast<void**>(&d.i31), size_t(im.gr.odd) * im.gr.h * 8), "hipMalloc");
+  }
+  launch_transform(src, 1, dst, 1, false);
+  d.image = true;
 }
 
-void CrtEngine::set_digits(const uint64_t* d, size_t count) {
+// dst <- dst * src * a with src a multiplicand image (engine::mul, engine.h:60)
+void CrtEngine::mul(size_t dst, size_t src, uint32_t a) {
   Impl& im = *im_;
+  check_digits(dst, "mul");
+  if (src >= im.regs.size() || !im.regs[src].image) throw std::runtime_error("mul: the source register is not a multiplicand (call set_multiplicand first)");
+  if (a == 0) throw std::runtime_error("mul: factor must be >= 1");
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  launch_transform(dst, 2, src, a, false);
+}
+
+void CrtEngine::copy(size_t dst, size_t src) {
+  Impl& im = *im_;
+  if (dst >= im.regs.size() || src >= im.regs.size()) throw std::runtime_error("copy: register index out of range");
+  if (dst == src) return;
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  Impl::Register& d = im.regs[dst]; const Impl::Register& r = im.regs[src];
+  if (r.image) {
+    if (!d.i61) {
+      chk(hipMalloc(reinterpret_cast<void**>(&d.i61), size_t(im.gr.odd) * im.gr.h * 16), "hipMalloc");
+      chk(hipMalloc(reinterpret_cast<void**>(&d.i31), size_t(im.gr.odd) * im.gr.h * 8), "hipMalloc");
+    }
+    chk(hipMemcpyAsync(d.i61, r.i61, size_t(im.gr.odd) * im.gr.h * 16, hipMemcpyDeviceToDevice, im.stream), "copy");
+    chk(hipMemcpyAsync(d.i31, r.i31, size_t(im.gr.odd) * im.gr.h * 8, hipMemcpyDeviceToDevice, im.stream), "copy");
+  } else {
+    chk(hipMemcpyAsync(d.x, r.x, size_t(im.g.n) * 8, hipMemcpyDeviceToDevice, im.stream), "copy");
+  }
+  d.image = r.image;
+}
+
+// dst <- dst + src, digit-wise on weakly carried digits (engine::add, engine.h:64)
+void CrtEngine::add(size_t dst, size_t src) {
+  Impl& im = *im_;
+  check_digits(dst, "add"); check_digits(src, "add");
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  hipLaunchKernelGGL(crt::k_add_digits, dim3((im.g.n + 255) / 256), dim3(256), 0, im.stream, im.regs[dst].x, im.regs[src].x, im.g.n);
+}
+
+// dst <- dst - src = dst + (2^p - 1 - src): the complement of the canonical digits of src (read back: LL-safe's rare operation)
+void CrtEngine::sub_reg(size_t dst, size_t src) {
+  Impl& im = *im_;
+  check_digits(dst, "sub_reg"); check_digits(src, "sub_reg");
+  const size_t n = im.g.n;
+  std::vector<uint64_t> d(n);
+  get_digits(src, d.data(), n, true);
+  for (size_t j = 0; j < n; ++j) d[j] = ((uint64_t(1) << im.width[j]) - 1) - d[j];
+  chk(hipMemcpy(im.w61, d.data(), n * 8, hipMemcpyHostToDevice), "copy");      // the carry sweep's input buffer is free between squarings
+  hipLaunchKernelGGL(crt::k_add_digits, dim3((im.g.n + 255) / 256), dim3(256), 0, im.stream, im.regs[dst].x, im.w61, im.g.n);
+  chk(hipStreamSynchronize(im.stream), "sync");
+}
+
+void CrtEngine::set_u32(size_t reg, uint32_t a) {
+  Impl& im = *im_;
+  if (reg >= im.regs.size()) throw std::runtime_error("set: register index out of range");
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  chk(hipMemsetAsync(im.regs[reg].x, 0, size_t(im.g.n) * 8, im.stream), "memset");
+  if (a) hipLaunchKernelGGL(crt::k_set_small, dim3(1), dim3(1), 0, im.stream, im.g, im.regs[reg].x, a);
+  im.regs[reg].image = false;
+}
+void CrtEngine::sub_u32(size_t reg, uint32_t a) {
+  Impl& im = *im_;
+  check_digits(reg, "sub");
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  if (a) hipLaunchKernelGGL(crt::k_sub_small, dim3(1), dim3(1), 0, im.stream, im.g, im.regs[reg].x, a);
+}
+
+void CrtEngine::set_digits(size_t reg, const uint64_t* d, size_t count) {
+  Impl& im = *im_;
+  if (reg >= im.regs.size()) throw std::runtime_error("set_digits: register index out of range");
   if (count != im.g.n) throw std::runtime_error("set_digits: wrong digit count");
   for (size_t j = 0; j < count; ++j) if (d[j] >> 62) throw std::runtime_error("set_digits: digit out of range");
   chk(hipSetDevice(im.device), "hipSetDevice");
   chk(hipStreamSynchronize(im.stream), "sync");
-  chk(hipMemcpy(im.x, d, count * 8, hipMemcpyHostToDevice), "copy");
+  chk(hipMemcpy(im.regs[reg].x, d, count * 8, hipMemcpyHostToDevice), "copy");
+  im.regs[reg].image = false;
 }
 
 // digits as they are on the device (weakly carried) or canonical: strong carry with wrap-around, 2^p - 1 stays all ones
-void CrtEngine::get_digits(uint64_t* d, size_t count, bool canonical) {
+void CrtEngine::get_digits(size_t reg, uint64_t* d, size_t count, bool canonical) {
   Impl& im = *im_;
+  check_digits(reg, "get_digits");
   if (count != im.g.n) throw std::runtime_error("get_digits: wrong digit count");
   sync();
-  chk(hipMemcpy(d, im.x, count * 8, hipMemcpyDeviceToHost), "copy");
+  chk(hipMemcpy(d, im.regs[reg].x, count * 8, hipMemcpyDeviceToHost), "copy");
   if (!canonical) return;
   uint64_t carry = 0;
   for (int lap = 0; lap < 4; ++lap) {
@@ -619,12 +738,12 @@ void CrtEngine::get_digits(uint64_t* d, size_t count, bool canonical) {
 }
 
 // canonical little-endian 32-bit words of the residue, 2^p - 1 -> 0 (what the plugin ABI exchanges: EngineApi.cpp:210-218)
-void CrtEngine::get_words(uint32_t* w, size_t count) {
+void CrtEngine::get_words(size_t reg, uint32_t* w, size_t count) {
   Impl& im = *im_;
   const size_t n = im.g.n, need = (size_t(im.g.p) + 31) / 32;
   if (count < need) throw std::runtime_error("get_words: buffer too small");
   std::vector<uint64_t> d(n);
-  get_digits(d.data(), n, true);
+  get_digits(reg, d.data(), n, true);
   bool ones = true;
   for (size_t j = 0; j < n && ones; ++j) ones = d[j] == ((uint64_t(1) << im.width[j]) - 1);
   std::memset(w, 0, count * 4);
@@ -639,25 +758,50 @@ void CrtEngine::get_words(uint32_t* w, size_t count) {
     bit += im.width[j];
   }
 }
-uint64_t CrtEngine::res64() {
+// reg <- the value of `count` little-endian 32-bit words (< 2^p; bits beyond p must be zero): cut into digits on the host
+void CrtEngine::set_words(size_t reg, const uint32_t* w, size_t count) {
+  Impl& im = *im_;
+  const size_t n = im.g.n, need = (size_t(im.g.p) + 31) / 32;
+  if (count > need) for (size_t k = need; k < count; ++k) if (w[k]) throw std::runtime_error("set_words: value does not fit 2^p");
+  if (count >= need && (im.g.p & 31) && (w[need - 1] >> (im.g.p & 31))) throw std::runtime_error("set_words: value does not fit 2^p");
+  std::vector<uint64_t> d(n, 0);
+  size_t bit = 0;
+  auto word = [&](size_t k) -> uint64_t { return k < count ? w[k] : 0; };
+  for (size_t j = 0; j < n; ++j) {
+    const size_t wi = bit >> 5, sh = bit & 31;
+    const unsigned __int128 v = ((unsigned __int128)word(wi) | ((unsigned __int128)word(wi + 1) << 32) | ((unsigned __int128)word(wi + 2) << 64)) >> sh;
+    d[j] = uint64_t(v) & ((uint64_t(1) << im.width[j]) - 1);
+    bit += im.width[j];
+  }
+  set_digits(reg, d.data(), n);
+}
+uint64_t CrtEngine::res64(size_t reg) {
   std::vector<uint32_t> w((size_t(im_->g.p) + 31) / 32 + 2, 0);
-  get_words(w.data(), w.size());
+  get_words(reg, w.data(), w.size());
   return uint64_t(w[0]) | (uint64_t(w[1]) << 32);
 }
+// same value mod 2^p - 1 (engine::is_equal, engine.h:148): canonical words on the host (two read-backs: a Gerbicz check, not the loop)
+bool CrtEngine::equal(size_t a, size_t b) {
+  const size_t need = (size_t(im_->g.p) + 31) / 32;
+  std::vector<uint32_t> wa(need), wb(need);
+  get_words(a, wa.data(), need); get_words(b, wb.data(), need);
+  return wa == wb;
+}
 
-void CrtEngine::time_square_mul(uint32_t a, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count) {
+void CrtEngine::time_square_mul(size_t reg, uint32_t a, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count) {
   Impl& im = *im_;
+  check_digits(reg, "time_square_mul");
   chk(hipSetDevice(im.device), "hipSetDevice");
   std::vector<double> acc(kKernels, 0.0);
   double total = 0;
   for (size_t it = 0; it < iters; ++it) {
-    launch_square(a, true);
+    launch_transform(reg, 0, 0, a, true);
     chk(hipEventSynchronize(im.ev[kKernels]), "sync");
     for (int k = 0; k < kKernels; ++k) { float ms = 0; chk(hipEventElapsedTime(&ms, im.ev[k], im.ev[k + 1]), "elapsed"); acc[k] += ms; }
     float ms = 0; chk(hipEventElapsedTime(&ms, im.ev[0], im.ev[kKernels]), "elapsed"); total += ms;
   }
   chk(hipGetLastError(), "kernel");
-  if (total_ms) *total_ms = iters ? total / double(iters) : 0;
+  if (total_ms) *total_ms = total;   // sum over the iterations, like Engine::time_square_mul
   for (size_t k = 0; k < kernel_count && k < size_t(kKernels); ++k) if (kernel_ms) kernel_ms[k] = iters ? acc[k] / double(iters) : 0;
 }
 

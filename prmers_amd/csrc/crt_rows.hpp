@@ -291,12 +291,12 @@ struct Pw31 {
   using C = F31::C;
   static __device__ __forceinline__ C mul(C a, C w) { return cmul31<false>(a, w); }
   static __device__ __forceinline__ C mulc(C a, C w) { return cmul31<true>(a, w); }
-  static __device__ __forceinline__ C spectrum(C zk, C zmk, C w) {
+  static __device__ __forceinline__ C lin(C zk, C zmk, C w) {          // X_k of the real sequence from the packed spectrum
     const C zc = cconj<F31>(zmk);
     const C e = cadd<F31>(zk, zc), o = cdiv_i<F31>(csub<F31>(zk, zc));
-    const C x = chalf<F31>(cadd<F31>(e, mul(o, w)));
-    return mul(x, x);
+    return chalf<F31>(cadd<F31>(e, mul(o, w)));
   }
+  static __device__ __forceinline__ C spectrum(C zk, C zmk, C w) { const C x = lin(zk, zmk, w); return mul(x, x); }
   static __device__ __forceinline__ C repack(C yk, C yhk, C w) {
     const C yc = cconj<F31>(yhk);
     const C e = cadd<F31>(yk, yc), d = mulc(csub<F31>(yk, yc), w);
@@ -306,14 +306,15 @@ struct Pw31 {
 __device__ __forceinline__ uint64_t half61(uint64_t v) { return (v & 1) ? (v + M61) >> 1 : v >> 1; }   // v <= 3 M61 -> <= 2 M61
 struct Pw61 {
   using C = F61::C;
-  static __device__ __forceinline__ C spectrum(C zk, C zmk, C w) {
+  static __device__ __forceinline__ C mul(C a, C w) { return cmul61<false>(Lz61{a.re, a.im}, w); }
+  static __device__ __forceinline__ C lin(C zk, C zmk, C w) {
     // e = zk + conj(zmk), o = (zk - conj(zmk)) / i = (d.im, -d.re); all <= 2 M61
     const Lz61 e{zk.re + zmk.re, zk.im + (K1 - zmk.im)};
     const Lz61 o{zk.im + zmk.im, K2 - (zk.re + (K1 - zmk.re))};
     const C t = cmul61<false>(Lz61{fold61(o.re), fold61(o.im)}, w);
-    const C x{canon61(half61(e.re + t.re)), canon61(half61(e.im + t.im))};
-    return cmul61<false>(Lz61{x.re, x.im}, x);
+    return {canon61(half61(e.re + t.re)), canon61(half61(e.im + t.im))};
   }
+  static __device__ __forceinline__ C spectrum(C zk, C zmk, C w) { const C x = lin(zk, zmk, w); return mul(x, x); }
   static __device__ __forceinline__ C repack(C yk, C yhk, C w) {
     const Lz61 e{yk.re + yhk.re, yk.im + (K1 - yhk.im)};
     const Lz61 df{fold61(yk.re + (K1 - yhk.re)), fold61(yk.im + yhk.im)};
@@ -325,34 +326,51 @@ template <class F> struct PwOf;
 template <> struct PwOf<F61> { using T = Pw61; };
 template <> struct PwOf<F31> { using T = Pw31; };
 
+// the stored spectrum of a multiplicand for the two rows of a work-group (a == nullptr: square instead): slot x < L is row a, L + x row b
+template <class F> struct Img {
+  const typename F::C* a; const typename F::C* b; uint32_t L;
+  __device__ __forceinline__ explicit operator bool() const { return a != nullptr; }
+  __device__ __forceinline__ typename F::C operator[](uint32_t slot) const { return slot < L ? a[slot] : b[slot - L]; }
+};
 template <class F>
-__device__ __forceinline__ void pointwise_pair(const Planes& P, uint32_t sa, uint32_t sb, typename F::C wa) {
+__device__ __forceinline__ void pointwise_pair(const Planes& P, uint32_t sa, uint32_t sb, typename F::C wa, Img<F> img) {
   using C = typename F::C;
   using PW = typename PwOf<F>::T;
   const C za = Slot<F>::get(P, sa), zb = Slot<F>::get(P, sb);
   const C wb = cneg<F>(cconj<F>(wa));                                   // omega_m^(h - k) = -conj(omega_m^k)
-  const C ya = PW::spectrum(za, zb, wa), yb = PW::spectrum(zb, za, wb);
+  C ya, yb;
+  if (img) {
+    const C ia = img[sa], ib = img[sb];
+    ya = PW::mul(PW::lin(za, zb, wa), PW::lin(ia, ib, wa)); yb = PW::mul(PW::lin(zb, za, wb), PW::lin(ib, ia, wb));
+  } else { ya = PW::spectrum(za, zb, wa); yb = PW::spectrum(zb, za, wb); }
   Slot<F>::put(P, sa, PW::repack(ya, yb, wa));
   Slot<F>::put(P, sb, PW::repack(yb, ya, wb));
 }
 template <class F>
-__device__ __forceinline__ void pointwise_self(const Planes& P, uint32_t s, typename F::C w) {   // k = h / 2: its own partner
+__device__ __forceinline__ void pointwise_self(const Planes& P, uint32_t s, typename F::C w, Img<F> img) {   // k = h / 2
   using PW = typename PwOf<F>::T;
   const typename F::C z = Slot<F>::get(P, s);
-  const typename F::C y = PW::spectrum(z, z, w);
+  typename F::C y;
+  if (img) { const typename F::C i = img[s]; y = PW::mul(PW::lin(z, z, w), PW::lin(i, i, w)); } else y = PW::spectrum(z, z, w);
   Slot<F>::put(P, s, PW::repack(y, y, w));
 }
 template <class F>
-__device__ __forceinline__ void pointwise_zero(const Planes& P, uint32_t s) {                      // k = 0 with k = h folded in
+__device__ __forceinline__ void pointwise_zero(const Planes& P, uint32_t s, Img<F> img) {   // k = 0 with k = h folded in
   using C = typename F::C;
   using PW = typename PwOf<F>::T;
   const C z = Slot<F>::get(P, s);
   const C one{1, 0}, mone{F::M - 1, 0};
-  const C y0 = PW::spectrum(z, z, one), yh = PW::spectrum(z, z, mone);
+  C y0, yh;
+  if (img) { const C i = img[s]; y0 = PW::mul(PW::lin(z, z, one), PW::lin(i, i, one)); yh = PW::mul(PW::lin(z, z, mone), PW::lin(i, i, mone)); }
+  else { y0 = PW::spectrum(z, z, one); yh = PW::spectrum(z, z, mone); }
   Slot<F>::put(P, s, PW::repack(y0, yh, one));
 }
 
-__global__ void __launch_bounds__(256) k_mid_fast(Grid gr, FastTables T, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
+// MODE 0: square in place; 1: forward only, the packed spectrum (in the in-place order of the transform) goes to I61 / I31 (set_multiplicand);
+// 2: multiply by the spectrum stored in I61 / I31
+template <int MODE>
+__global__ void __launch_bounds__(256) k_mid_fast(Grid gr, FastTables T, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31, F61::C* __restrict__ I61,
+                                                  F31::C* __restrict__ I31) {
   const Planes P = planes_of(smem_crt);
   const uint32_t tid = threadIdx.x, logL = gr.logH2, L = 1u << logL, H1 = 1u << gr.logH1;   // L = 1024: two rows per work-group
   const uint32_t per_row = H1 >> 1;
@@ -366,6 +384,21 @@ __global__ void __launch_bounds__(256) k_mid_fast(Grid gr, FastTables T, F61::C*
     Slot<F61>::put(P, e, z61[addr]); Slot<F31>::put(P, e, z31[addr]);
   }
   transform_both<false>(P, tid, logL, T.w2_61, T.w2_31);
+  if (MODE == 1) {
+    F61::C* i61 = I61 + size_t(row) * gr.h; F31::C* i31 = I31 + size_t(row) * gr.h;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const uint32_t e = tid + 256u * it, r = e >> logL, i = e & (L - 1);
+      const size_t addr = size_t(r ? k1b : k1a) * L + i;
+      i61[addr] = Slot<F61>::get(P, e); i31[addr] = Slot<F31>::get(P, e);
+    }
+    return;
+  }
+  Img<F61> g61{nullptr, nullptr, L}; Img<F31> g31{nullptr, nullptr, L};
+  if (MODE == 2) {
+    g61.a = I61 + size_t(row) * gr.h + size_t(k1a) * L; g61.b = I61 + size_t(row) * gr.h + size_t(k1b) * L;
+    g31.a = I31 + size_t(row) * gr.h + size_t(k1a) * L; g31.b = I31 + size_t(row) * gr.h + size_t(k1b) * L;
+  }
   // pointwise: 1024 pairs (4 per thread)
   const F61::C ua61 = T.u61[k1a], ub61 = T.u61[k1b]; const F31::C ua31 = T.u31[k1a], ub31 = T.u31[k1b];
 #pragma unroll
@@ -373,22 +406,22 @@ __global__ void __launch_bounds__(256) k_mid_fast(Grid gr, FastTables T, F61::C*
     const uint32_t q = tid + 256u * it;                                 // 0 .. 1023
     if (b) {                                                            // (row a, k2 = q) <-> (row b, k2 = L - 1 - q)
       const uint32_t sa = pos_of_freq(q, logL), sb = L + pos_of_freq(L - 1 - q, logL);
-      pointwise_pair<F61>(P, sa, sb, cmul61<false>(Lz61{ua61.re, ua61.im}, T.v61[q]));
-      pointwise_pair<F31>(P, sa, sb, cmul31<false>(ua31, T.v31[q]));
+      pointwise_pair<F61>(P, sa, sb, cmul61<false>(Lz61{ua61.re, ua61.im}, T.v61[q]), g61);
+      pointwise_pair<F31>(P, sa, sb, cmul31<false>(ua31, T.v31[q]), g31);
     } else if (q < (L >> 1)) {                                          // row H1/2: k2 = q <-> L - 1 - q
       const uint32_t sa = L + pos_of_freq(q, logL), sb = L + pos_of_freq(L - 1 - q, logL);
-      pointwise_pair<F61>(P, sa, sb, cmul61<false>(Lz61{ub61.re, ub61.im}, T.v61[q]));
-      pointwise_pair<F31>(P, sa, sb, cmul31<false>(ub31, T.v31[q]));
+      pointwise_pair<F61>(P, sa, sb, cmul61<false>(Lz61{ub61.re, ub61.im}, T.v61[q]), g61);
+      pointwise_pair<F31>(P, sa, sb, cmul31<false>(ub31, T.v31[q]), g31);
     } else {                                                            // row 0: k2 = q' <-> L - q'
       const uint32_t qq = q - (L >> 1);
       if (qq == 0) {
-        pointwise_zero<F61>(P, 0); pointwise_zero<F31>(P, 0);
+        pointwise_zero<F61>(P, 0, g61); pointwise_zero<F31>(P, 0, g31);
         const uint32_t sm = pos_of_freq(L >> 1, logL);
-        pointwise_self<F61>(P, sm, T.v61[L >> 1]); pointwise_self<F31>(P, sm, T.v31[L >> 1]);
+        pointwise_self<F61>(P, sm, T.v61[L >> 1], g61); pointwise_self<F31>(P, sm, T.v31[L >> 1], g31);
       } else {
         const uint32_t sa = pos_of_freq(qq, logL), sb = pos_of_freq(L - qq, logL);
-        pointwise_pair<F61>(P, sa, sb, T.v61[qq]);
-        pointwise_pair<F31>(P, sa, sb, T.v31[qq]);
+        pointwise_pair<F61>(P, sa, sb, T.v61[qq], g61);
+        pointwise_pair<F31>(P, sa, sb, T.v31[qq], g31);
       }
     }
   }

@@ -76,22 +76,7 @@ def load_library():
         "mi355_engine_mul_copy": (C.c_int, [vp, sz, sz, sz, u32]),
         "mi355_crt_carry": (C.c_int, [u32, sz, u32, u32, vp, vp, vp, vp, sz, dp]),
         "mi355_crt_transform_size": (sz, [u32, u32]),
-        "mi355_crt_create": (vp, [u32, u32, sz, u32, C.c_char_p]),
-        "mi355_crt_destroy": (None, [vp]),
-        "mi355_crt_size": (sz, [vp]),
-        "mi355_crt_describe": (C.c_int, [vp, C.c_char_p, sz]),
-        "mi355_crt_sync": (C.c_int, [vp]),
-        "mi355_crt_set_u32": (C.c_int, [vp, u32]),
-        "mi355_crt_square_mul": (C.c_int, [vp, u32]),
-        "mi355_crt_sub_u32": (C.c_int, [vp, u32]),
-        "mi355_crt_get_digits": (C.c_int, [vp, vp, sz, C.c_int]),
-        "mi355_crt_set_digits": (C.c_int, [vp, vp, sz]),
-        "mi355_crt_get_words": (C.c_int, [vp, vp, sz]),
-        "mi355_crt_res64": (C.c_int, [vp, u64p]),
-        "mi355_crt_time_square_mul": (C.c_int, [vp, u32, sz, dp, dp, sz]),
-        "mi355_crt_kernel_count": (sz, []),
-        "mi355_crt_kernel_name": (C.c_char_p, [sz]),
-        "mi355_crt_algorithmic_bytes": (sz, [vp]),
+        "mi355_engine_describe": (C.c_int, [vp, C.c_char_p, sz]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -110,9 +95,7 @@ EXPORTS = [
     "mi355_engine_set_data", "mi355_engine_checkpoint_size", "mi355_engine_get_checkpoint",
     "mi355_engine_set_checkpoint", "mi355_engine_time_square_mul", "mi355_engine_kernel_count",
     "mi355_engine_kernel_name", "mi355_engine_algorithmic_bytes", "mi355_engine_selftest",
-    "mi355_crt_carry", "mi355_crt_transform_size", "mi355_crt_create", "mi355_crt_destroy", "mi355_crt_size", "mi355_crt_describe", "mi355_crt_sync",
-    "mi355_crt_set_u32", "mi355_crt_square_mul", "mi355_crt_sub_u32", "mi355_crt_get_digits", "mi355_crt_set_digits", "mi355_crt_get_words",
-    "mi355_crt_res64", "mi355_crt_time_square_mul", "mi355_crt_kernel_count", "mi355_crt_kernel_name", "mi355_crt_algorithmic_bytes",
+    "mi355_crt_carry", "mi355_crt_transform_size", "mi355_engine_describe",
     "mi355_engine_addsub", "mi355_engine_addsub_copy", "mi355_engine_mul_add", "mi355_engine_square_mul_copy", "mi355_engine_mul_copy",
 ]
 
@@ -271,80 +254,39 @@ class Engine:
 
     def algorithmic_bytes(self): return self.L.mi355_engine_algorithmic_bytes(self.h)
 
-
-class CrtEngine:
-    """The GF(M61^2) x GF(M31^2) squaring engine with a prime-factor axis of radix 1, 3 or 9 (the reference's Aevum
-    plugin, third_party/aevum/src/EngineApi.h:28-59): one residue, set / square_mul / sub / read-back.  No CPU fallback."""
-
-    def __init__(self, p, odd=1, n=0, device=0, plan=None):
-        self.L = load_library()
-        self.h = self.L.mi355_crt_create(p, odd, n, device, plan.encode() if plan else None)
-        if not self.h:
-            raise EngineError(self.L.mi355_engine_last_error().decode())
-        self.p, self.odd = p, odd
-        self.n = self.L.mi355_crt_size(self.h)
-
-    def close(self):
-        if getattr(self, "h", None):
-            self.L.mi355_crt_destroy(self.h)
-            self.h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        self.close()
-
-    def _ok(self, r):
-        if not r:
-            raise EngineError(self.L.mi355_engine_last_error().decode())
-
     def describe(self):
+        """plan text of this engine (kernel set included)"""
         buf = C.create_string_buffer(256)
-        self._ok(self.L.mi355_crt_describe(self.h, buf, 256))
+        self._ok(self.L.mi355_engine_describe(self.h, buf, 256))
         return buf.value.decode()
 
-    def sync(self): self._ok(self.L.mi355_crt_sync(self.h))
-    def set(self, a): self._ok(self.L.mi355_crt_set_u32(self.h, a))
-    def square_mul(self, a=1): self._ok(self.L.mi355_crt_square_mul(self.h, a))
-    def sub(self, a): self._ok(self.L.mi355_crt_sub_u32(self.h, a))
 
-    def digits(self, canonical=True):
+
+class CrtEngine(Engine):
+    """The GF(M61^2) x GF(M31^2) engine with a prime-factor axis of radix 1, 3 or 9 (the reference's Aevum plugin,
+    third_party/aevum/src/EngineApi.h:28-59) -- the same register machine as `Engine`, selected through the fft_spec "crt:odd[:words=N]".
+    Digits are plain u64 values here (widths reach 39 bits).  No CPU fallback."""
+
+    def __init__(self, p, odd=1, n=0, device=0, plan=None, reg_count=4):
+        spec = "crt:%d" % odd + (":words=%d" % n if n else "") + (":" + plan if plan else "")
+        Engine.__init__(self, p, reg_count, device, False, spec)
+        self.odd = odd
+
+    def raw_digits(self, src=0):
+        """the engine's own digits: plain values in base 2^width_j, canonical (widths reach 39 bits)"""
         d = np.zeros(self.n, dtype=np.uint64)
-        self._ok(self.L.mi355_crt_get_digits(self.h, _ptr(d), self.n, int(canonical)))
+        self._ok(self.L.mi355_engine_get_digits(self.h, src, _ptr(d), self.n))
         return d
 
-    def set_digits(self, d):
-        d = np.ascontiguousarray(d, dtype=np.uint64)
-        self._ok(self.L.mi355_crt_set_digits(self.h, _ptr(d), d.size))
+    def digits(self, src=0):
+        """value | width << 32 like engine::get (engine.h:24), for callers that cut a residue into words themselves (prp.py): the canonical
+        residue in 32-bit pieces -- this family's own digits do not fit that encoding"""
+        w = self.words(src).astype(np.uint64)
+        width = np.full(w.size, 32, dtype=np.uint64)
+        if self.p % 32:
+            width[-1] = self.p % 32
+        return w | (width << np.uint64(32))
 
-    def words(self):
-        w = np.zeros((self.p + 31) // 32, dtype=np.uint32)
-        self._ok(self.L.mi355_crt_get_words(self.h, _ptr(w), w.size))
-        return w
-
-    def get_int(self):
-        return int.from_bytes(self.words().astype("<u4").tobytes(), "little")
-
-    def res64(self):
-        out = C.c_uint64(0)
-        self._ok(self.L.mi355_crt_res64(self.h, C.byref(out)))
-        return out.value
-
-    def kernel_names(self):
-        return [self.L.mi355_crt_kernel_name(k).decode() for k in range(self.L.mi355_crt_kernel_count())]
-
-    def time_square_mul(self, iters, a=1):
-        k = self.L.mi355_crt_kernel_count()
-        total = C.c_double(0)
-        per = (C.c_double * k)()
-        self._ok(self.L.mi355_crt_time_square_mul(self.h, a, iters, C.byref(total), per, k))
-        return total.value, dict(zip(self.kernel_names(), list(per)))
-
-    def algorithmic_bytes(self): return self.L.mi355_crt_algorithmic_bytes(self.h)
+    def time_square_mul(self, reg, iters, a=1, sub=0, per_kernel=True):
+        """(total_ms of `iters` squarings, {stage: average ms}); every iteration is bracketed by events here"""
+        return Engine.time_square_mul(self, reg, iters, a, sub, per_kernel)

@@ -36,12 +36,12 @@ def test_square_mul_matches_the_oracle_digit_for_digit(p, odd, n, plan):
         rng = np.random.default_rng(p + odd)
         w = o.widths().astype(np.uint64)
         start = rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))
-        o.set_digits(start); e.set_digits(start)
+        o.set_digits(start); e.set_digits(0, start)
         for it, a in enumerate((1, 3, 1, 1)):
-            o.square_mul(a); e.square_mul(a)
-            assert np.array_equal(e.digits(), o.digits()), (p, odd, plan, it)
-        assert np.array_equal(e.words(), o.words())
-        assert e.res64() == o.value() & ((1 << 64) - 1)
+            o.square_mul(a); e.square_mul(0, a)
+            assert np.array_equal(e.raw_digits(0), o.digits()), (p, odd, plan, it)
+        assert np.array_equal(e.words(0), o.words())
+        assert e.res64(0) == o.value() & ((1 << 64) - 1)
 
 
 def test_both_kernel_sets_agree(monkeypatch):
@@ -54,10 +54,10 @@ def test_both_kernel_sets_agree(monkeypatch):
         with CrtEngine(p, odd, n) as g:
             assert g.describe().endswith("generic")
             start = rng.integers(0, 1 << 20, n, dtype=np.uint64)
-            e.set_digits(start); g.set_digits(start)
+            e.set_digits(0, start); g.set_digits(0, start)
             for a in (1, 3, 1):
-                e.square_mul(a); g.square_mul(a)
-                assert np.array_equal(e.digits(), g.digits())
+                e.square_mul(0, a); g.square_mul(0, a)
+                assert np.array_equal(e.raw_digits(0), g.raw_digits(0))
 
 
 @pytest.mark.parametrize("p,odd", [(127, 1), (521, 3), (1279, 9), (2203, 9), (2281, 3)])
@@ -73,13 +73,63 @@ def test_lucas_lehmer_verdicts(p, odd):
         with e:
             Mq = (1 << q) - 1
             s = 4
-            e.set(4)
+            e.set(0, 4)
             for i in range(q - 2):
-                e.square_mul(1); e.sub(2)
+                e.square_mul(0, 1); e.sub(0, 2)
                 s = (s * s - 2) % Mq
                 if i % 97 == 0 or i == q - 3:
-                    assert e.get_int() == s, (q, i)
-            assert (e.get_int() == 0) == prime
+                    assert e.get_int(0) == s, (q, i)
+            assert (e.get_int(0) == 0) == prime
+
+
+@pytest.mark.parametrize("p,odd,n", [(9941, 9, 0), (216091, 3, 3 << 11), (6972593, 9, 9 << 15)])
+def test_register_machine_copy_multiplicand_mul_add_sub_equal(p, odd, n):
+    """set_multiplicand / mul / copy / add / sub_reg / is_equal / set_words of the same plugin ABI (EngineApi.h:28-59) against Python
+    integers, on the generic and on the radix-8 kernel set"""
+    Mp = (1 << p) - 1
+    rng = np.random.default_rng(p)
+    with CrtEngine(p, odd, n, reg_count=6) as e:
+        x = int.from_bytes(rng.bytes((p + 7) // 8), "little") % Mp
+        y = int.from_bytes(rng.bytes((p + 7) // 8), "little") % Mp
+        e.set_int(0, x); e.set_int(1, y)
+        assert e.get_int(0) == x and e.get_int(1) == y
+        e.copy(2, 0)
+        e.set_multiplicand(3, 1)                       # register 3 <- image of y
+        e.mul(2, 3, 3)                                 # x * y * 3
+        assert e.get_int(2) == x * y * 3 % Mp
+        e.copy(4, 3); e.copy(5, 0); e.mul(5, 4)        # a copied image multiplies the same
+        assert e.get_int(5) == x * y % Mp
+        e.square_mul(0); e.copy(4, 0)
+        assert e.get_int(4) == x * x % Mp
+        e.add(4, 2)
+        assert e.get_int(4) == (x * x + 3 * x * y) % Mp
+        e.sub_reg(4, 2)
+        assert e.get_int(4) == x * x % Mp and e.is_equal(4, 0)
+        e.sub(4, 1)
+        assert not e.is_equal(4, 0)
+        e.set(5, 0); e.set_int(4, Mp)                  # 2^p - 1 == 0
+        assert e.is_equal(4, 5)
+        with pytest.raises(Exception, match="multiplicand"):
+            e.square_mul(3)
+        with pytest.raises(Exception, match="multiplicand"):
+            e.mul(0, 1)
+        # (x y)^2 = x^2 y^2 through two different operation orders
+        e.set_int(0, x); e.set_int(1, y)
+        e.set_multiplicand(3, 1); e.copy(2, 0); e.mul(2, 3); e.square_mul(2)
+        e.square_mul(0); e.square_mul(1); e.set_multiplicand(3, 1); e.mul(0, 3)
+        assert e.is_equal(0, 2)
+
+
+def test_prp_with_gerbicz_li_checks_on_the_crt_engine():
+    """the caller loop of the reference (RunPrpOrLlMarin.cpp:338-409 mirrored in prmers_amd/prp.py) runs unchanged on this engine:
+    a complete PRP of M9941 and of a composite, Gerbicz-Li checks on, an injected error caught and repaired"""
+    from prmers_amd import prp
+    with CrtEngine(9941, 9, reg_count=prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, 9941, "prp", checklevel=1)
+        assert r["is_prime"] and r["gerbicz_checks"] >= 1 and r["gerbicz_errors"] == 0
+    with CrtEngine(9949, 3, reg_count=prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, 9949, "prp", checklevel=1, erroriter=4000)
+        assert not r["is_prime"] and r["gerbicz_errors"] == 1
 
 
 def test_sizes_with_too_few_bits_per_word_are_refused():
@@ -92,14 +142,14 @@ def test_set_sub_and_all_ones():
     p, odd = 9941, 9
     with CrtEngine(p, odd) as e:
         Mp = (1 << p) - 1
-        e.set(5); assert e.get_int() == 5
-        e.sub(7); assert e.get_int() == Mp - 2            # borrow through every digit and around
-        e.square_mul(1); assert e.get_int() == 4
+        e.set(0, 5); assert e.get_int(0) == 5
+        e.sub(0, 7); assert e.get_int(0) == Mp - 2        # borrow through every digit and around
+        e.square_mul(0, 1); assert e.get_int(0) == 4
         o = orc_crt.OracleCrt(p, odd)
         ones = (np.uint64(1) << o.widths().astype(np.uint64)) - np.uint64(1)
-        e.set_digits(ones)
-        assert e.get_int() == 0 and e.res64() == 0        # 2^p - 1 reads as zero
-        e.square_mul(3); assert e.get_int() == 0
+        e.set_digits(0, ones)
+        assert e.get_int(0) == 0 and e.res64(0) == 0      # 2^p - 1 reads as zero
+        e.square_mul(0, 3); assert e.get_int(0) == 0
 
 
 @pytest.mark.parametrize("odd,n", [(9, 9 << 20), (3, 3 << 21)])
@@ -111,17 +161,17 @@ def test_pfa_sizes_of_config_4_against_the_gmp_pins_and_the_oracle(odd, n):
     pins = {c["iteration"]: c for c in json.load(open(os.path.join(HERE, "golden", "big_p_pins.json")))["pins"][str(p)]}
     with CrtEngine(p, odd, n) as e:
         assert e.n == n
-        e.set(3)
+        e.set(0, 3)
         for k in range(1, max(pins) + 1):
-            e.square_mul(1)
+            e.square_mul(0, 1)
             if k in pins:
-                assert e.res64() == int(pins[k]["res64"], 16), k
-                assert hashlib.sha256(e.words().astype("<u4").tobytes()).hexdigest() == pins[k]["sha256_words"], k
+                assert e.res64(0) == int(pins[k]["res64"], 16), k
+                assert hashlib.sha256(e.words(0).astype("<u4").tobytes()).hexdigest() == pins[k]["sha256_words"], k
         o = orc_crt.OracleCrt(p, odd, n)
         rng = np.random.default_rng(1)
         w = o.widths().astype(np.uint64)
         start = rng.integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))
-        o.set_digits(start); e.set_digits(start)
+        o.set_digits(start); e.set_digits(0, start)
         o.square_mul(3); e.square_mul(3)
         assert np.array_equal(e.digits(), o.digits())
         total, per = e.time_square_mul(20)

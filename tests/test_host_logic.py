@@ -299,7 +299,7 @@ def test_cpp_driver_worktodo_checkpoint_proof_and_json_on_gpu(tmp_path):
     m = gold["m100003"]
     assert line["exponent"] == 100003 and line["worktype"] == "PRP-3" and line["status"] == "C"
     assert line["res64"] == "1CF45E9503C71FD6" and line["residue-type"] == 1 and line["errors"] == {"gerbicz": 0}
-    assert line["aid"] == "0123456789ABCDEF0123456789ABCDEF" and line["fft-length"] == 8192
+    assert line["aid"] == "0123456789ABCDEF0123456789ABCDEF" and line["fft-length"] == 4096
     assert line["res64"] == m["res64"] and line["res2048"] == m["res2048"].lower()
     assert wt.read_text() == "Test=607\n" and "100003" in (tmp_path / "worktodo_save.txt").read_text()
     pts = sorted(int(f.name) for f in (tmp_path / "100003" / "proof").iterdir())
