@@ -69,7 +69,7 @@ def test_c_abi_exports_and_no_gpu_behaviour():
             E.Engine(127, 2)
         with pytest.raises(E.EngineError, match="no CPU fallback|HIP"):
             E.CrtEngine(1279, 9)
-    assert lib.mi355_crt_kernel_count() == 6
+    assert "crt-hip:n=9437184:odd=9" == E.resolve_plan(205271257, "crt:9") and "n=6291456" in E.resolve_plan(205271257, "crt:3")
 
 
 def _build_adapter(td):
