@@ -397,6 +397,8 @@ struct CrtEngine::Impl {
   uint64_t *w61 = nullptr, *carry = nullptr, *residual = nullptr;
   uint32_t* w31 = nullptr;
   bool fast = false;              // crt_rows.hpp kernels (rows of 1024, columns of 2 .. 2048)
+  bool cols_joint = false;        // MI355_CRT_KERNELS=joint / split: force both fields in one column launch, or one field per launch (A/B runs)
+  bool cols_split = false;
   F61::C *W1_61 = nullptr, *W2_61 = nullptr, *V61 = nullptr, *LO61 = nullptr, *HI61 = nullptr;
   F31::C *W1_31 = nullptr, *W2_31 = nullptr, *V31 = nullptr, *LO31 = nullptr, *HI31 = nullptr;
   hipEvent_t ev[kKernels + 1] = {};
@@ -427,7 +429,7 @@ CrtEngine::CrtEngine(uint32_t p, size_t reg_count, uint32_t odd, size_t n_forced
     if (gr.ln < 3) throw std::runtime_error("crt engine: power-of-two axis too short");
     uint32_t logH2 = std::min<uint32_t>(10, gr.logh);
     if (spec && std::strncmp(spec, "h2=", 3) == 0) logH2 = uint32_t(std::atoi(spec + 3));
-    if (logH2 < 1 || logH2 > std::min<uint32_t>(10, gr.logh) || gr.logh - logH2 > 10) throw std::runtime_error("crt engine: bad row split");
+    if (logH2 < 1 || logH2 > std::min<uint32_t>(10, gr.logh) || gr.logh - logH2 > 11) throw std::runtime_error("crt engine: bad row split");
     gr.logH2 = logH2; gr.logH1 = gr.logh - logH2;
     gr.minv = 0;
     if (odd > 1) for (uint32_t y = 1; y < odd; ++y) if ((uint64_t(gr.m % odd) * y) % odd == 1) gr.minv = y;
@@ -471,6 +473,15 @@ CrtEngine::CrtEngine(uint32_t p, size_t reg_count, uint32_t odd, size_t n_forced
       chk(hipMemcpy(im.U61, u61.data(), (h + 1) * 16, hipMemcpyHostToDevice), "copy"); chk(hipMemcpy(im.U31, u31.data(), (h + 1) * 8, hipMemcpyHostToDevice), "copy");
       const char* ks = std::getenv("MI355_CRT_KERNELS");
       im.fast = gr.logH2 == 10 && gr.logH1 >= 1 && gr.logH1 <= 11 && !(ks && std::strcmp(ks, "generic") == 0);
+      im.cols_joint = ks && std::strcmp(ks, "joint") == 0;
+      im.cols_split = ks && std::strcmp(ks, "split") == 0;
+      if (im.fast) {   // the one-field column kernels use 68 KiB of LDS
+        const int l61 = int((4096 + 4096 / 16) * 16), l31 = int((8192 + 8192 / 16) * 8);
+        chk(hipFuncSetAttribute(reinterpret_cast<const void*>(&crt::k_cols_one<F61, false, 4096>), hipFuncAttributeMaxDynamicSharedMemorySize, l61), "lds attribute");
+        chk(hipFuncSetAttribute(reinterpret_cast<const void*>(&crt::k_cols_one<F61, true, 4096>), hipFuncAttributeMaxDynamicSharedMemorySize, l61), "lds attribute");
+        chk(hipFuncSetAttribute(reinterpret_cast<const void*>(&crt::k_cols_one<F31, false, 8192>), hipFuncAttributeMaxDynamicSharedMemorySize, l31), "lds attribute");
+        chk(hipFuncSetAttribute(reinterpret_cast<const void*>(&crt::k_cols_one<F31, true, 8192>), hipFuncAttributeMaxDynamicSharedMemorySize, l31), "lds attribute");
+      }
       if (im.fast) {
         // omega_L^x = omega_m^(x m / L) for the two pass lengths (x < L; beyond h through omega_m^h = -1), omega_m^(H1 k2)
         auto pick61 = [&](size_t e) { return e <= h ? u61[e] : crt::cneg<F61>(u61[e - h]); };
@@ -577,13 +588,29 @@ void CrtEngine::launch_transform(size_t reg, int mode, size_t other, uint32_t a,
   if (im.fast) {
     const crt::FastTables T{im.W1_61, im.W2_61, im.V61, im.U61, im.LO61, im.HI61, im.W1_31, im.W2_31, im.V31, im.U31, im.LO31, im.HI31};
     const uint32_t CA = crt::kFastSlots >> gr.logH1, gcols = gr.odd * ((1u << gr.logH2) / CA), gmid = gr.odd * (1u << gr.logH1) / 2;
-    hipLaunchKernelGGL((crt::k_cols_fast<false>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    // columns: one field per launch where that gives wider row segments (H2 columns must hold at least one group of each kind)
+    constexpr uint32_t S61 = 4096, S31 = 8192;
+    // measured: at H1 = 512 the joint kernel is faster (0.121 / 0.114 ms against 0.150 / 0.132), from H1 = 1024 on the split ones are
+    const bool split = !im.cols_joint && (gr.logH1 >= 10 || im.cols_split) && (S31 >> gr.logH1) >= 1 && (S31 >> gr.logH1) <= (1u << gr.logH2);
+    const uint32_t g61 = gr.odd * (1u << gr.logH2) / std::max(1u, S61 >> gr.logH1), g31 = gr.odd * (1u << gr.logH2) / std::max(1u, S31 >> gr.logH1);
+    const size_t lds61 = size_t(S61 + S61 / 16) * 16, lds31 = size_t(S31 + S31 / 16) * 8;
+    if (split) {
+      hipLaunchKernelGGL((crt::k_cols_one<F61, false, S61>), dim3(g61), dim3(S61 / 8), lds61, s, gr, im.W1_61, im.LO61, im.HI61, im.Z61);
+      hipLaunchKernelGGL((crt::k_cols_one<F31, false, S31>), dim3(g31), dim3(S31 / 8), lds31, s, gr, im.W1_31, im.LO31, im.HI31, im.Z31);
+    } else {
+      hipLaunchKernelGGL((crt::k_cols_fast<false>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    }
     mark();
     if (mode == 0) hipLaunchKernelGGL((crt::k_mid_fast<0>), dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31, i61, i31);
     else if (mode == 1) { hipLaunchKernelGGL((crt::k_mid_fast<1>), dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31, i61, i31); return; }
     else hipLaunchKernelGGL((crt::k_mid_fast<2>), dim3(gmid), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31, i61, i31);
     mark();
-    hipLaunchKernelGGL((crt::k_cols_fast<true>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    if (split) {
+      hipLaunchKernelGGL((crt::k_cols_one<F61, true, S61>), dim3(g61), dim3(S61 / 8), lds61, s, gr, im.W1_61, im.LO61, im.HI61, im.Z61);
+      hipLaunchKernelGGL((crt::k_cols_one<F31, true, S31>), dim3(g31), dim3(S31 / 8), lds31, s, gr, im.W1_31, im.LO31, im.HI31, im.Z31);
+    } else {
+      hipLaunchKernelGGL((crt::k_cols_fast<true>), dim3(gcols), b256, crt::kFastLdsBytes, s, gr, T, im.Z61, im.Z31);
+    }
     mark();   // slots: k_rows_fwd = forward columns, k_pointwise = the fused row kernel, k_rows_inv = inverse columns
   } else {
     launch_rows<F61>(gr, im.Z61, im.U61, false, s);

@@ -284,6 +284,77 @@ __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C
   }
 }
 
+// ---- columns, one field per launch: twice the columns per work-group for Z/M61 (4096 slots, 512 threads: 128-byte row segments at
+// H1 = 512) and four times for Z/M31 (8192 slots, 1024 threads), i.e. no half-used cache lines on the strided side of the four-step
+template <class F> struct FieldOps;
+template <> struct FieldOps<F61> {
+  static __device__ __forceinline__ F61::C tw(F61::C a, F61::C lo, F61::C hi, bool conj) {
+    if (conj) { a = cmul61<true>(Lz61{a.re, a.im}, lo); return cmul61<true>(Lz61{a.re, a.im}, hi); }
+    a = cmul61<false>(Lz61{a.re, a.im}, lo); return cmul61<false>(Lz61{a.re, a.im}, hi);
+  }
+  template <int LR, bool INV> static __device__ __forceinline__ void step(const Planes& P, uint32_t tid, uint32_t logL, uint32_t logS, const F61::C* W) {
+    step61<LR, INV>(P, tid, logL, logS, W);
+  }
+};
+template <> struct FieldOps<F31> {
+  static __device__ __forceinline__ F31::C tw(F31::C a, F31::C lo, F31::C hi, bool conj) {
+    return conj ? cmul31<true>(cmul31<true>(a, lo), hi) : cmul31<false>(cmul31<false>(a, lo), hi);
+  }
+  template <int LR, bool INV> static __device__ __forceinline__ void step(const Planes& P, uint32_t tid, uint32_t logL, uint32_t logS, const F31::C* W) {
+    crt::step<F31, LR, INV>(P, tid, logL, logS, W);
+  }
+};
+template <class F, bool INV>
+__device__ __forceinline__ void transform_one(const Planes& P, uint32_t tid, uint32_t logL, const typename F::C* __restrict__ W) {
+  uint32_t sizes[4]; int ns = 0;
+  for (uint32_t logS = logL; logS; logS -= step_bits(logS)) sizes[ns++] = logS;
+  for (int t = 0; t < ns; ++t) {
+    const uint32_t logS = sizes[INV ? ns - 1 - t : t];
+    const uint32_t lr = step_bits(logS);
+    __syncthreads();
+    if (lr == 3) FieldOps<F>::template step<3, INV>(P, tid, logL, logS, W);
+    else if (lr == 2) FieldOps<F>::template step<2, INV>(P, tid, logL, logS, W);
+    else FieldOps<F>::template step<1, INV>(P, tid, logL, logS, W);
+  }
+  __syncthreads();
+}
+
+template <class F, bool INV, uint32_t SLOTS>
+__global__ void __launch_bounds__(SLOTS / 8) k_cols_one(Grid gr, const typename F::C* __restrict__ W1, const typename F::C* __restrict__ LO,
+                                                        const typename F::C* __restrict__ HI, typename F::C* __restrict__ Z) {
+  using C = typename F::C;
+  constexpr uint32_t NT = SLOTS / 8, PLANE = SLOTS + SLOTS / 16;
+  Planes P;
+  P.re = reinterpret_cast<uint64_t*>(smem_crt); P.im = P.re + PLANE; P.c3 = reinterpret_cast<uint2*>(smem_crt);   // one field: planes may overlap in name only
+  const uint32_t tid = threadIdx.x, logL = gr.logH1, H2 = 1u << gr.logH2;
+  const uint32_t CA = SLOTS >> logL, per_row = H2 / CA;
+  const uint32_t row = blockIdx.x / per_row, col0 = (blockIdx.x - row * per_row) * CA;
+  C* z = Z + size_t(row) * gr.h;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t e = tid + NT * it, c = e % CA, i = e / CA;
+    C a = z[size_t(i) * H2 + col0 + c];
+    uint32_t slot = (c << logL) + i;
+    if (INV) {
+      const uint32_t tw = 2u * i * (col0 + c);
+      a = FieldOps<F>::tw(a, LO[tw & 1023], HI[tw >> 10], true);
+      slot = (c << logL) + pos_of_freq(i, logL);
+    }
+    Slot<F>::put(P, slot, a);
+  }
+  transform_one<F, INV>(P, tid, logL, W1);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t e = tid + NT * it, c = e % CA, i = e / CA;
+    C a = Slot<F>::get(P, (c << logL) + (INV ? i : pos_of_freq(i, logL)));
+    if (!INV) {
+      const uint32_t tw = 2u * i * (col0 + c);
+      a = FieldOps<F>::tw(a, LO[tw & 1023], HI[tw >> 10], false);
+    }
+    z[size_t(i) * H2 + col0 + c] = a;
+  }
+}
+
 // ---- middle: rows k1 and H1 - k1 (work-group 0 of a grid row: rows 0 and H1 / 2, each its own partner) ----
 // The conjugate-symmetric untangle / square / re-tangle (crt_engine.hip: spectrum_sq, repack) per field: Z/M31[i] on the generic forms
 // with the fused product, Z/M61[i] on the lazy forms (sums of up to three canonical values, one fold before a product).

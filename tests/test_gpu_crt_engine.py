@@ -55,9 +55,12 @@ def test_both_kernel_sets_agree(monkeypatch):
             assert g.describe().endswith("generic")
             start = rng.integers(0, 1 << 20, n, dtype=np.uint64)
             e.set_digits(0, start); g.set_digits(0, start)
-            for a in (1, 3, 1):
-                e.square_mul(0, a); g.square_mul(0, a)
-                assert np.array_equal(e.raw_digits(0), g.raw_digits(0))
+            monkeypatch.setenv("MI355_CRT_KERNELS", "split")      # one field per column launch (the default from columns of 1024 on)
+            with CrtEngine(p, odd, n) as sp:
+                sp.set_digits(0, start)
+                for a in (1, 3, 1):
+                    e.square_mul(0, a); g.square_mul(0, a); sp.square_mul(0, a)
+                    assert np.array_equal(e.raw_digits(0), g.raw_digits(0)) and np.array_equal(e.raw_digits(0), sp.raw_digits(0))
 
 
 @pytest.mark.parametrize("p,odd", [(127, 1), (521, 3), (1279, 9), (2203, 9), (2281, 3)])
@@ -176,3 +179,18 @@ def test_pfa_sizes_of_config_4_against_the_gmp_pins_and_the_oracle(odd, n):
         assert np.array_equal(e.raw_digits(0), o.digits())
         total, per = e.time_square_mul(0, 20)
         print("crt engine p=%d %s: %.4f ms/iter (event-bracketed stages) %s" % (p, e.describe(), total / 20, {k: round(v, 4) for k, v in per.items()}))
+
+
+def test_headline_exponent_on_the_crt_family_against_the_gmp_pins():
+    """p = 136279841 (BASELINE configs[2]) at 2^22 words of 32.5 bits, columns of 2048: 3^(2^k) against the libgmp pins"""
+    import hashlib
+    p = 136279841
+    pins = {c["iteration"]: c for c in json.load(open(os.path.join(HERE, "golden", "big_p_pins.json")))["pins"][str(p)]}
+    with CrtEngine(p, 1, reg_count=1) as e:
+        assert e.n == 1 << 22 and "h1=2048" in e.describe()
+        e.set(0, 3)
+        for k in range(1, max(pins) + 1):
+            e.square_mul(0, 1)
+            if k in pins:
+                assert e.res64(0) == int(pins[k]["res64"], 16), k
+                assert hashlib.sha256(e.words(0).astype("<u4").tobytes()).hexdigest() == pins[k]["sha256_words"], k
