@@ -48,7 +48,11 @@ void selftest_primitives(int device) {
   chk(hipSetDevice(device), "hipSetDevice");
   const uint64_t P = gf::P;
   std::vector<uint64_t> edge = {0, 1, 2, P - 1, P - 2, P, 0xffffffffull, 0x100000000ull, 0xffffffff00000000ull, 0x8000000000000000ull,
-                                0xfffffffeffffffffull, 0x00000000fffffffeull, 0x123456789abcdef0ull % P};
+                                0xfffffffeffffffffull, 0x00000000fffffffeull, 0x123456789abcdef0ull % P,
+                                // operands whose products take the rare paths of gf::mul's tail: 2^64 - 1 = (2^32 + 1)(2^32 - 1) (low half >= P, no
+                                // carry), (P - 1)^2 (borrow out of lo - hh - c), products with an empty low word or an all-ones high word
+                                0x100000001ull, 0x00000001ffffffffull, 0xfffffffe00000001ull, 0x0000000100000000ull + 0xfffffffeull, 0xffffffff00000000ull - 1,
+                                0x00000000ffff0001ull, 0xffff0000ffff0001ull};
   std::vector<uint64_t> a, b;
   for (uint64_t x : edge) for (uint64_t y : edge) { a.push_back(x); b.push_back(y); }
   uint64_t s = 0x9e3779b97f4a7c15ull;
