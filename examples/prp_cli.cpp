@@ -32,13 +32,14 @@ static std::vector<uint32_t> residue_words(engine* eng, size_t reg, uint32_t p) 
 }
 
 int main(int argc, char** argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: %s <p> | -worktodo FILE [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER] [-json FILE] [-lib so]\n", argv[0]); return 2; }
+  if (argc < 2) { std::fprintf(stderr, "usage: %s <p> | -worktodo FILE [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER] [-json FILE] [-fft SPEC] [-lib so]\n", argv[0]); return 2; }
   uint32_t p = uint32_t(std::strtoul(argv[1], nullptr, 10));
-  bool ll = false; uint64_t erroriter = 0, checklevel = 0, maxiters = 0, backup = 0; std::string lib, worktodo, ckpt_dir, json_file; uint32_t proof_power = 0;
+  bool ll = false; uint64_t erroriter = 0, checklevel = 0, maxiters = 0, backup = 0; std::string lib, worktodo, ckpt_dir, json_file, fft; uint32_t proof_power = 0;
   fmt::WorkEntry entry;
   for (int i = 1; i < argc; ++i) {
     if (!std::strcmp(argv[i], "-ll")) ll = true;
     else if (!std::strcmp(argv[i], "-worktodo") && i + 1 < argc) worktodo = argv[++i];
+    else if (!std::strcmp(argv[i], "-fft") && i + 1 < argc) fft = argv[++i];   // e.g. crt:9 (the reference's -fft, README.md:907-926)
     else if (!std::strcmp(argv[i], "-ckpt") && i + 1 < argc) ckpt_dir = argv[++i];
     else if (!std::strcmp(argv[i], "-backup") && i + 1 < argc) backup = std::strtoull(argv[++i], nullptr, 10);
     else if (!std::strcmp(argv[i], "-proof") && i + 1 < argc) proof_power = uint32_t(std::strtoul(argv[++i], nullptr, 10));
@@ -55,7 +56,7 @@ int main(int argc, char** argv) {
     std::printf("worktodo: %s\n", entry.raw.c_str());
   }
   try {
-    std::unique_ptr<engine> eng(new engine_hip(p, 8, 0, false, lib));
+    std::unique_ptr<engine> eng(new engine_hip(p, 8, 0, false, lib, fft));
     const size_t R0 = 0, R1 = 1, R2 = 2, R3 = 3, R4 = 4, R5 = 5, RBASE = 6, RTMP = 7;
     eng->set(R1, 1);
     eng->set(R0, ll ? 4 : 3);

@@ -104,9 +104,13 @@ class engine_hip final : public engine {
   void set(const size_t dst, uint64_t* const d) const override { ok(_api.set_digits(_h, dst, d, _n), "set"); }
 
  public:
-  engine_hip(const uint32_t q, const size_t reg_count, const size_t device, const bool verbose, const std::string& lib_hint = "")
+  // fft_spec: "" = the Goldilocks path with its automatic plan, "m2=..,c=.." a forced plan, "crt[:odd][:words=N]" the
+  // GF(M61^2) x GF(M31^2) family with a prime-factor axis (the reference hands its -fft string to its plugin the same way,
+  // src/aevum/EngineAevum.cpp:252-300)
+  engine_hip(const uint32_t q, const size_t reg_count, const size_t device, const bool verbose, const std::string& lib_hint = "",
+             const std::string& fft_spec = "")
       : _api(lib_hint) {
-    _h = _api.create(q, reg_count, uint32_t(device), verbose ? 1 : 0, nullptr, nullptr);
+    _h = _api.create(q, reg_count, uint32_t(device), verbose ? 1 : 0, fft_spec.empty() ? nullptr : fft_spec.c_str(), nullptr);
     if (!_h) throw std::runtime_error(std::string("MI355 create failed: ") + _api.last_error());
     _n = _api.transform_size(_h);
   }

@@ -145,10 +145,10 @@ int mi355_engine_square_mul_copy(mi355_engine_handle h, size_t src, size_t cp, u
 int mi355_engine_mul_copy(mi355_engine_handle h, size_t dst, size_t src, size_t cp, uint32_t f) { return guarded([&] { eng(h)->mul_copy(dst, src, cp, f); }); }
 
 int mi355_engine_get_digits(mi355_engine_handle h, size_t src, uint64_t* d, size_t count) {
-  return guarded([&] { if (!d) throw std::runtime_error("get_digits: null buffer"); if (crt(h)) crt(h)->get_digits(src, d, count, true); else eng(h)->get_digits(src, d, count); });
+  return guarded([&] { if (!d) throw std::runtime_error("get_digits: null buffer"); if (crt(h)) crt(h)->get_digits_encoded(src, d, count); else eng(h)->get_digits(src, d, count); });
 }
 int mi355_engine_set_digits(mi355_engine_handle h, size_t dst, const uint64_t* d, size_t count) {
-  return guarded([&] { if (!d) throw std::runtime_error("set_digits: null buffer"); if (crt(h)) crt(h)->set_digits(dst, d, count); else eng(h)->set_digits(dst, d, count); });
+  return guarded([&] { if (!d) throw std::runtime_error("set_digits: null buffer"); if (crt(h)) crt(h)->set_digits_encoded(dst, d, count); else eng(h)->set_digits(dst, d, count); });
 }
 int mi355_engine_res64(mi355_engine_handle h, size_t src, uint64_t* out) {
   return guarded([&] { if (!out) throw std::runtime_error("res64: null output"); *out = crt(h) ? crt(h)->res64(src) : eng(h)->res64(src); });
@@ -190,6 +190,12 @@ int mi355_crt_carry(uint32_t exponent, size_t words, uint32_t odd, uint32_t fact
     if (!in61 || !in31 || !digits_out || !residual_out) throw std::runtime_error("crt_carry: null buffer");
     mi355::crt_carry_host(exponent, words, odd, factor, in61, in31, digits_out, residual_out, int(device), kernel_ms);
   });
+}
+int mi355_crt_get_raw_digits(mi355_engine_handle h, size_t src, uint64_t* d, size_t count, int canonical) {
+  return guarded([&] { if (!d || !crt(h)) throw std::runtime_error("get_raw_digits: needs a crt engine and a buffer"); crt(h)->get_digits(src, d, count, canonical != 0); });
+}
+int mi355_crt_set_raw_digits(mi355_engine_handle h, size_t dst, const uint64_t* d, size_t count) {
+  return guarded([&] { if (!d || !crt(h)) throw std::runtime_error("set_raw_digits: needs a crt engine and a buffer"); crt(h)->set_digits(dst, d, count); });
 }
 size_t mi355_crt_transform_size(uint32_t exponent, uint32_t odd) { size_t r = 0; guarded([&] { r = mi355::crt_transform_size(exponent, odd); }); return r; }
 size_t mi355_engine_algorithmic_bytes(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = crt(h) ? crt(h)->algorithmic_bytes() : eng(h)->algorithmic_bytes(); }); return r; }

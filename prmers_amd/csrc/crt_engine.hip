@@ -764,6 +764,25 @@ void CrtEngine::get_digits(size_t reg, uint64_t* d, size_t count, bool canonical
   }
 }
 
+void CrtEngine::get_digits_encoded(size_t reg, uint64_t* d, size_t count) {
+  Impl& im = *im_;
+  get_digits(reg, d, count, true);
+  for (size_t j = 0; j < count; ++j) {
+    if (im.width[j] > 32) throw std::runtime_error("get_digits: this transform size has words of more than 32 bits, which the value | width << 32 encoding cannot hold (use get_words)");
+    d[j] |= uint64_t(im.width[j]) << 32;
+  }
+}
+void CrtEngine::set_digits_encoded(size_t reg, const uint64_t* d, size_t count) {
+  Impl& im = *im_;
+  if (count != im.g.n) throw std::runtime_error("set_digits: wrong digit count");
+  std::vector<uint64_t> v(count);
+  for (size_t j = 0; j < count; ++j) {
+    if ((d[j] >> 32) != im.width[j]) throw std::runtime_error("set_digits: digit width mismatch");
+    v[j] = d[j] & 0xffffffffull;
+  }
+  set_digits(reg, v.data(), count);
+}
+
 // canonical little-endian 32-bit words of the residue, 2^p - 1 -> 0 (what the plugin ABI exchanges: EngineApi.cpp:210-218)
 void CrtEngine::get_words(size_t reg, uint32_t* w, size_t count) {
   Impl& im = *im_;

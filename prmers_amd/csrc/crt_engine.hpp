@@ -41,6 +41,9 @@ class CrtEngine {
   bool equal(size_t a, size_t b);
   void set_digits(size_t reg, const uint64_t* d, size_t count);
   void get_digits(size_t reg, uint64_t* d, size_t count, bool canonical);
+  // engine::get / engine::set form (engine.h:24-25): canonical value | width << 32 -- only for sizes whose words have at most 32 bits
+  void get_digits_encoded(size_t reg, uint64_t* d, size_t count);
+  void set_digits_encoded(size_t reg, const uint64_t* d, size_t count);
   void set_words(size_t reg, const uint32_t* w, size_t count);
   void get_words(size_t reg, uint32_t* w, size_t count);
   uint64_t res64(size_t reg);

@@ -77,6 +77,8 @@ def load_library():
         "mi355_crt_carry": (C.c_int, [u32, sz, u32, u32, vp, vp, vp, vp, sz, dp]),
         "mi355_crt_transform_size": (sz, [u32, u32]),
         "mi355_engine_describe": (C.c_int, [vp, C.c_char_p, sz]),
+        "mi355_crt_get_raw_digits": (C.c_int, [vp, sz, vp, sz, C.c_int]),
+        "mi355_crt_set_raw_digits": (C.c_int, [vp, sz, vp, sz]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)   # AttributeError here = the library does not export what the header declares
@@ -95,7 +97,7 @@ EXPORTS = [
     "mi355_engine_set_data", "mi355_engine_checkpoint_size", "mi355_engine_get_checkpoint",
     "mi355_engine_set_checkpoint", "mi355_engine_time_square_mul", "mi355_engine_kernel_count",
     "mi355_engine_kernel_name", "mi355_engine_algorithmic_bytes", "mi355_engine_selftest",
-    "mi355_crt_carry", "mi355_crt_transform_size", "mi355_engine_describe",
+    "mi355_crt_carry", "mi355_crt_transform_size", "mi355_engine_describe", "mi355_crt_get_raw_digits", "mi355_crt_set_raw_digits",
     "mi355_engine_addsub", "mi355_engine_addsub_copy", "mi355_engine_mul_add", "mi355_engine_square_mul_copy", "mi355_engine_mul_copy",
 ]
 
@@ -275,12 +277,17 @@ class CrtEngine(Engine):
     def raw_digits(self, src=0):
         """the engine's own digits: plain values in base 2^width_j, canonical (widths reach 39 bits)"""
         d = np.zeros(self.n, dtype=np.uint64)
-        self._ok(self.L.mi355_engine_get_digits(self.h, src, _ptr(d), self.n))
+        self._ok(self.L.mi355_crt_get_raw_digits(self.h, src, _ptr(d), self.n, 1))
         return d
+
+    def set_digits(self, dst, d):
+        """plain digit values (the engine's own base 2^width_j digits)"""
+        d = np.ascontiguousarray(d, dtype=np.uint64)
+        self._ok(self.L.mi355_crt_set_raw_digits(self.h, dst, _ptr(d), d.size))
 
     def digits(self, src=0):
         """value | width << 32 like engine::get (engine.h:24), for callers that cut a residue into words themselves (prp.py): the canonical
-        residue in 32-bit pieces -- this family's own digits do not fit that encoding"""
+        residue in 32-bit pieces -- this family's own digits do not always fit that encoding"""
         w = self.words(src).astype(np.uint64)
         width = np.full(w.size, 32, dtype=np.uint64)
         if self.p % 32:

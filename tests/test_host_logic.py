@@ -279,6 +279,23 @@ def test_cpp_caller_formats_match_the_python_mirror_and_known_answers(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_driver_on_the_crt_family_through_the_same_adapter(tmp_path):
+    """the C++ caller (examples/prp_cli.cpp over include/mi355/engine_hip.h) with -fft crt:9 / crt:3: the same adapter, the same loop,
+    the GF(M61^2) x GF(M31^2) engine behind it -- PRP of M9941 (prime) with Gerbicz-Li checks, LL of M9689, an injected error repaired"""
+    from prmers_amd import engine as E
+    exe = _build_cli(str(tmp_path))
+    run = lambda *a: subprocess.run([exe, *a, "-lib", E.LIB_PATH], capture_output=True, text=True, cwd=str(tmp_path))   # noqa: E731
+    o = run("9941", "-fft", "crt:9:words=576", "-checklevel", "1")
+    assert o.returncode == 0 and "probably prime" in o.stdout and "Check passed" in o.stdout, o.stdout + o.stderr
+    o = run("9689", "-ll", "-fft", "crt:3:words=384")
+    assert o.returncode == 0 and "probably prime" in o.stdout, o.stdout + o.stderr
+    o = run("9949", "-fft", "crt:9:words=576", "-checklevel", "1", "-erroriter", "5000")
+    assert o.returncode == 0 and "composite" in o.stdout and "Check FAILED" in o.stdout and "gerbicz_errors=1" in o.stdout, o.stdout + o.stderr
+    o = run("9941", "-fft", "crt:7")
+    assert o.returncode != 0 and "odd radix" in (o.stdout + o.stderr)
+
+
+@pytest.mark.gpu
 def test_cpp_driver_worktodo_checkpoint_proof_and_json_on_gpu(tmp_path):
     """examples/prp_cli.cpp with the caller-side formats (include/mi355/caller_formats.h): a worktodo entry is run in two
     slices through a version-2 checkpoint, leaves the proof residues, the reference's golden result line of M100003
