@@ -153,19 +153,27 @@ int mi355_engine_set_digits(mi355_engine_handle h, size_t dst, const uint64_t* d
 int mi355_engine_res64(mi355_engine_handle h, size_t src, uint64_t* out) {
   return guarded([&] { if (!out) throw std::runtime_error("res64: null output"); *out = crt(h) ? crt(h)->res64(src) : eng(h)->res64(src); });
 }
-size_t mi355_engine_register_data_size(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->register_data_size(); }); return r; }
+size_t mi355_engine_register_data_size(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = crt(h) ? crt(h)->register_data_size() : eng(h)->register_data_size(); }); return r; }
 int mi355_engine_get_data(mi355_engine_handle h, size_t src, void* data, size_t size) {
-  return guarded([&] { if (!data) throw std::runtime_error("get_data: null buffer"); eng(h)->get_data(src, data, size); });
+  return guarded([&] { if (!data) throw std::runtime_error("get_data: null buffer"); if (crt(h)) crt(h)->get_data(src, data, size); else eng(h)->get_data(src, data, size); });
 }
 int mi355_engine_set_data(mi355_engine_handle h, size_t dst, const void* data, size_t size) {
-  return guarded([&] { if (!data) throw std::runtime_error("set_data: null buffer"); eng(h)->set_data(dst, data, size); });
+  return guarded([&] { if (!data) throw std::runtime_error("set_data: null buffer"); if (crt(h)) crt(h)->set_data(dst, data, size); else eng(h)->set_data(dst, data, size); });
 }
-size_t mi355_engine_checkpoint_size(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = eng(h)->checkpoint_size(); }); return r; }
+size_t mi355_engine_checkpoint_size(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = crt(h) ? crt(h)->register_data_size() * crt(h)->reg_count() : eng(h)->checkpoint_size(); }); return r; }
 int mi355_engine_get_checkpoint(mi355_engine_handle h, void* data, size_t size) {
-  return guarded([&] { if (!data) throw std::runtime_error("get_checkpoint: null buffer"); eng(h)->get_checkpoint(data, size); });
+  return guarded([&] { if (!data) throw std::runtime_error("get_checkpoint: null buffer"); if (crt(h)) {
+      const size_t rs = crt(h)->register_data_size(), nr = crt(h)->reg_count();
+      if (size != rs * nr) throw std::runtime_error("get_checkpoint: size mismatch");
+      for (size_t r = 0; r < nr; ++r) crt(h)->get_data(r, static_cast<unsigned char*>(data) + r * rs, rs);
+    } else eng(h)->get_checkpoint(data, size); });
 }
 int mi355_engine_set_checkpoint(mi355_engine_handle h, const void* data, size_t size) {
-  return guarded([&] { if (!data) throw std::runtime_error("set_checkpoint: null buffer"); eng(h)->set_checkpoint(data, size); });
+  return guarded([&] { if (!data) throw std::runtime_error("set_checkpoint: null buffer"); if (crt(h)) {
+      const size_t rs = crt(h)->register_data_size(), nr = crt(h)->reg_count();
+      if (size != rs * nr) throw std::runtime_error("set_checkpoint: size mismatch");
+      for (size_t r = 0; r < nr; ++r) crt(h)->set_data(r, static_cast<const unsigned char*>(data) + r * rs, rs);
+    } else eng(h)->set_checkpoint(data, size); });
 }
 
 int mi355_engine_time_square_mul(mi355_engine_handle h, size_t reg, uint32_t factor, uint32_t sub, size_t iters,

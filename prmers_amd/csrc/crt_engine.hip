@@ -834,6 +834,41 @@ bool CrtEngine::equal(size_t a, size_t b) {
   return wa == wb;
 }
 
+size_t CrtEngine::register_data_size() const { return size_t(im_->g.n) * 12 + 8; }
+void CrtEngine::get_data(size_t src, void* data, size_t size) {
+  Impl& im = *im_;
+  if (src >= im.regs.size()) throw std::runtime_error("get_data: register index out of range");
+  if (size != register_data_size()) throw std::runtime_error("get_data: size mismatch");
+  sync();
+  unsigned char* out = static_cast<unsigned char*>(data);
+  const size_t n = im.g.n, slots = size_t(im.gr.odd) * im.gr.h;   // 2 slots' worth of words per slot: 16 + 8 bytes = 12 bytes a word
+  std::memset(out, 0, size);
+  const Impl::Register& r = im.regs[src];
+  if (r.image) { chk(hipMemcpy(out, r.i61, slots * 16, hipMemcpyDeviceToHost), "copy"); chk(hipMemcpy(out + slots * 16, r.i31, slots * 8, hipMemcpyDeviceToHost), "copy"); }
+  else chk(hipMemcpy(out, r.x, n * 8, hipMemcpyDeviceToHost), "copy");
+  const uint64_t tag = r.image ? 1 : 0;
+  std::memcpy(out + n * 12, &tag, 8);
+}
+void CrtEngine::set_data(size_t dst, const void* data, size_t size) {
+  Impl& im = *im_;
+  if (dst >= im.regs.size()) throw std::runtime_error("set_data: register index out of range");
+  if (size != register_data_size()) throw std::runtime_error("set_data: size mismatch");
+  const unsigned char* in = static_cast<const unsigned char*>(data);
+  const size_t n = im.g.n, slots = size_t(im.gr.odd) * im.gr.h;
+  uint64_t tag = 0;
+  std::memcpy(&tag, in + n * 12, 8);
+  if (tag > 1) throw std::runtime_error("set_data: not an image written by this engine");
+  sync();
+  Impl::Register& r = im.regs[dst];
+  if (tag == 1) {
+    if (!r.i61) { chk(hipMalloc(reinterpret_cast<void**>(&r.i61), slots * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&r.i31), slots * 8), "hipMalloc"); }
+    chk(hipMemcpy(r.i61, in, slots * 16, hipMemcpyHostToDevice), "copy"); chk(hipMemcpy(r.i31, in + slots * 16, slots * 8, hipMemcpyHostToDevice), "copy");
+  } else {
+    chk(hipMemcpy(r.x, in, n * 8, hipMemcpyHostToDevice), "copy");
+  }
+  r.image = tag == 1;
+}
+
 void CrtEngine::time_square_mul(size_t reg, uint32_t a, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count) {
   Impl& im = *im_;
   check_digits(reg, "time_square_mul");

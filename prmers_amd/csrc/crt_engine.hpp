@@ -47,6 +47,11 @@ class CrtEngine {
   void set_words(size_t reg, const uint32_t* w, size_t count);
   void get_words(size_t reg, uint32_t* w, size_t count);
   uint64_t res64(size_t reg);
+  // raw register images (engine.h:134-146): 12 bytes per word + an 8-byte kind tag; a residue uses the first 8 n bytes (digits), a
+  // multiplicand all 12 n (its packed spectrum).  Implementation-defined, as the reference's images are.
+  size_t register_data_size() const;
+  void get_data(size_t src, void* data, size_t size);
+  void set_data(size_t dst, const void* data, size_t size);
   void sync();
   void time_square_mul(size_t reg, uint32_t a, size_t iters, double* total_ms, double* kernel_ms, size_t kernel_count);
 

@@ -139,6 +139,33 @@ def test_prp_with_gerbicz_li_checks_on_the_crt_engine():
         assert not r["is_prime"] and r["gerbicz_errors"] == 1
 
 
+def test_checkpoints_and_raw_images_on_the_crt_engine(tmp_path):
+    """get_data / set_data / checkpoints (engine.h:134-146) with residues and a multiplicand image in the register file, and the caller's
+    checkpoint file (prmers_amd/prp.py, version-2 layout) carrying a PRP across two engines"""
+    from prmers_amd import prp
+    p = 9941
+    with CrtEngine(p, 9, reg_count=prp.REGISTERS) as e, CrtEngine(p, 9, reg_count=prp.REGISTERS) as f:
+        e.set(0, 3)
+        for _ in range(50):
+            e.square_mul(0)
+        e.copy(1, 0); e.set_multiplicand(2, 1)
+        ck = e.get_checkpoint()
+        assert ck.size == e.get_checkpoint_size() == prp.REGISTERS * e.get_register_data_size()
+        assert f.set_checkpoint(ck)
+        assert f.get_int(0) == e.get_int(0) == pow(3, 1 << 50, (1 << p) - 1)
+        e.mul(0, 2); f.mul(0, 2)                         # the restored image multiplies the same
+        assert f.get_int(0) == e.get_int(0) == pow(3, 1 << 51, (1 << p) - 1)
+        assert not f.set_data(0, np.zeros(5, dtype=np.uint8))
+    path = prp.checkpoint_name(p, "prp", str(tmp_path))
+    with CrtEngine(p, 3, reg_count=prp.REGISTERS) as e:
+        part = prp.run_prp_or_ll(e, p, "prp", max_iters=4000, ckpt_path=path, backup_every=1000, checklevel=1)
+        assert not part["complete"]
+    with CrtEngine(p, 3, reg_count=prp.REGISTERS) as e:
+        msgs = []
+        r = prp.run_prp_or_ll(e, p, "prp", ckpt_path=path, checklevel=1, log=msgs.append)
+        assert "Resuming from a checkpoint." in msgs and r["is_prime"] and r["complete"] and r["gerbicz_errors"] == 0
+
+
 def test_sizes_with_too_few_bits_per_word_are_refused():
     from prmers_amd import EngineError
     with pytest.raises(EngineError, match="bits per word"):
