@@ -121,7 +121,7 @@ MI355_ENGINE_API int mi355_crt_carry(uint32_t exponent, size_t transform_words, 
    transform sizes README.md:907-926, e.g. "crt:9" = the radix-9 family, "crt:3:words=6291456").  words = 0 / absent: the smallest
    admissible odd * 2^k.  Served by that engine: the 19 core entry points (create ... equal), get_digits / set_digits (sizes with words of
    at most 32 bits), res64, raw images and checkpoints (12 bytes per word + a kind tag per register), time_square_mul (sub must be 0), kernel_count /
-   kernel_name, algorithmic_bytes, describe; the fused register operations answer 0 with "not implemented for the crt field family". */
+   kernel_name, algorithmic_bytes, describe, the fused register operations (as compositions). */
 MI355_ENGINE_API size_t mi355_crt_transform_size(uint32_t exponent, uint32_t odd_radix);
 /* the engine's own digits of a crt handle: plain u64 values in base 2^width_j, logical order (canonical != 0: after the strong carry;
    0: as they are on the device, weakly carried) -- test and debugging access; mi355_engine_get_digits / set_digits on such a handle

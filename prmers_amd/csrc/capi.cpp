@@ -136,13 +136,13 @@ int mi355_engine_equal(mi355_engine_handle h, size_t lhs, size_t rhs, int* out) 
   return guarded([&] { if (!out) throw std::runtime_error("equal: null output"); *out = (crt(h) ? crt(h)->equal(lhs, rhs) : eng(h)->equal(lhs, rhs)) ? 1 : 0; });
 }
 
-int mi355_engine_addsub(mi355_engine_handle h, size_t so, size_t dout, size_t a, size_t b) { return guarded([&] { eng(h)->addsub(so, dout, a, b); }); }
+int mi355_engine_addsub(mi355_engine_handle h, size_t so, size_t dout, size_t a, size_t b) { return guarded([&] { if (crt(h)) crt(h)->addsub(long(so), -1, long(dout), -1, a, b); else eng(h)->addsub(so, dout, a, b); }); }
 int mi355_engine_addsub_copy(mi355_engine_handle h, size_t s1, size_t d1, size_t s2, size_t d2, size_t a, size_t b) {
-  return guarded([&] { eng(h)->addsub_copy(s1, d1, s2, d2, a, b); });
+  return guarded([&] { if (crt(h)) crt(h)->addsub(long(s1), long(s2), long(d1), long(d2), a, b); else eng(h)->addsub_copy(s1, d1, s2, d2, a, b); });
 }
-int mi355_engine_mul_add(mi355_engine_handle h, size_t dst, size_t ms, size_t as, uint32_t f) { return guarded([&] { eng(h)->mul_add(dst, ms, as, f); }); }
-int mi355_engine_square_mul_copy(mi355_engine_handle h, size_t src, size_t cp, uint32_t f) { return guarded([&] { eng(h)->square_mul_copy(src, cp, f); }); }
-int mi355_engine_mul_copy(mi355_engine_handle h, size_t dst, size_t src, size_t cp, uint32_t f) { return guarded([&] { eng(h)->mul_copy(dst, src, cp, f); }); }
+int mi355_engine_mul_add(mi355_engine_handle h, size_t dst, size_t ms, size_t as, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->mul_add(dst, ms, as, f); else eng(h)->mul_add(dst, ms, as, f); }); }
+int mi355_engine_square_mul_copy(mi355_engine_handle h, size_t src, size_t cp, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->square_mul_copy(src, cp, f); else eng(h)->square_mul_copy(src, cp, f); }); }
+int mi355_engine_mul_copy(mi355_engine_handle h, size_t dst, size_t src, size_t cp, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->mul_copy(dst, src, cp, f); else eng(h)->mul_copy(dst, src, cp, f); }); }
 
 int mi355_engine_get_digits(mi355_engine_handle h, size_t src, uint64_t* d, size_t count) {
   return guarded([&] { if (!d) throw std::runtime_error("get_digits: null buffer"); if (crt(h)) crt(h)->get_digits_encoded(src, d, count); else eng(h)->get_digits(src, d, count); });

@@ -392,6 +392,7 @@ struct CrtEngine::Impl {
     bool image = false;           // holds a multiplicand image instead of digits
   };
   std::vector<Register> regs;
+  uint64_t* scratch = nullptr;    // [n] digits: temporary of addsub
   F61::C *Z61 = nullptr, *U61 = nullptr;
   F31::C *Z31 = nullptr, *U31 = nullptr;
   uint64_t *w61 = nullptr, *carry = nullptr, *residual = nullptr;
@@ -456,6 +457,7 @@ CrtEngine::CrtEngine(uint32_t p, size_t reg_count, uint32_t odd, size_t n_forced
     for (auto& e : im.ev) chk(hipEventCreate(&e), "event");
     const size_t h = gr.h, nruns = (n + crt::kRun - 1) / crt::kRun;
     im.regs.resize(reg_count);
+    chk(hipMalloc(reinterpret_cast<void**>(&im.scratch), n * 8), "hipMalloc");   // addsub's temporary
     for (auto& r : im.regs) { chk(hipMalloc(reinterpret_cast<void**>(&r.x), n * 8), "hipMalloc"); chk(hipMemset(r.x, 0, n * 8), "memset"); }
     chk(hipMalloc(reinterpret_cast<void**>(&im.Z61), size_t(odd) * h * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.Z31), size_t(odd) * h * 8), "hipMalloc");
     chk(hipMalloc(reinterpret_cast<void**>(&im.U61), (h + 1) * 16), "hipMalloc"); chk(hipMalloc(reinterpret_cast<void**>(&im.U31), (h + 1) * 8), "hipMalloc");
@@ -516,6 +518,7 @@ void CrtEngine::release() {
   (void)hipSetDevice(im.device);
   if (im.stream) (void)hipStreamSynchronize(im.stream);
   for (auto& r : im.regs) for (void* q : {static_cast<void*>(r.x), static_cast<void*>(r.i61), static_cast<void*>(r.i31)}) if (q) (void)hipFree(q);
+  if (im.scratch) (void)hipFree(im.scratch);
   for (void* q : {static_cast<void*>(im.Z61), static_cast<void*>(im.Z31), static_cast<void*>(im.U61), static_cast<void*>(im.U31),
                   static_cast<void*>(im.w61), static_cast<void*>(im.w31), static_cast<void*>(im.carry), static_cast<void*>(im.residual),
                   static_cast<void*>(im.W1_61), static_cast<void*>(im.W2_61), static_cast<void*>(im.V61), static_cast<void*>(im.W1_31),
@@ -717,6 +720,48 @@ void CrtEngine::sub_reg(size_t dst, size_t src) {
   hipLaunchKernelGGL(crt::k_add_digits, dim3((im.g.n + 255) / 256), dim3(256), 0, im.stream, im.regs[dst].x, im.w61, im.g.n);
   chk(hipStreamSynchronize(im.stream), "sync");
 }
+
+// sum -> sum_out (and sum_copy), difference -> diff_out (and diff_copy); -1: not wanted.  a and b may be among the outputs.
+void CrtEngine::addsub(long sum_out, long sum_copy, long diff_out, long diff_copy, size_t a, size_t b) {
+  Impl& im = *im_;
+  check_digits(a, "addsub"); check_digits(b, "addsub");
+  const long outs[4] = {sum_out, sum_copy, diff_out, diff_copy};
+  for (int i = 0; i < 4; ++i) {
+    if (outs[i] >= long(im.regs.size())) throw std::runtime_error("addsub: register index out of range");
+    for (int j = 0; j < i; ++j) if (outs[i] >= 0 && outs[i] == outs[j]) throw std::runtime_error("addsub: output registers must differ");
+  }
+  if ((sum_copy >= 0 && sum_out < 0) || (diff_copy >= 0 && diff_out < 0)) throw std::runtime_error("addsub: copy output without a primary output");
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  const size_t n = im.g.n, bytes = n * 8;
+  const dim3 grid((im.g.n + 255) / 256), block(256);
+  // scratch = a + (2^p - 1 - b): the complement of the canonical digits of b (a read-back, as in sub_reg), before anything is overwritten
+  if (diff_out >= 0) {
+    std::vector<uint64_t> d(n);
+    get_digits(b, d.data(), n, true);
+    for (size_t j = 0; j < n; ++j) d[j] = ((uint64_t(1) << im.width[j]) - 1) - d[j];
+    chk(hipMemcpy(im.scratch, d.data(), bytes, hipMemcpyHostToDevice), "copy");
+    hipLaunchKernelGGL(crt::k_add_digits, grid, block, 0, im.stream, im.scratch, im.regs[a].x, im.g.n);
+  }
+  if (sum_out >= 0) {
+    if (size_t(sum_out) == b) {   // b + a
+      hipLaunchKernelGGL(crt::k_add_digits, grid, block, 0, im.stream, im.regs[b].x, im.regs[a].x, im.g.n);
+    } else {
+      if (size_t(sum_out) != a) chk(hipMemcpyAsync(im.regs[sum_out].x, im.regs[a].x, bytes, hipMemcpyDeviceToDevice, im.stream), "copy");
+      hipLaunchKernelGGL(crt::k_add_digits, grid, block, 0, im.stream, im.regs[sum_out].x, im.regs[b].x, im.g.n);
+    }
+    im.regs[sum_out].image = false;
+    if (sum_copy >= 0) { chk(hipMemcpyAsync(im.regs[sum_copy].x, im.regs[sum_out].x, bytes, hipMemcpyDeviceToDevice, im.stream), "copy"); im.regs[sum_copy].image = false; }
+  }
+  if (diff_out >= 0) {
+    chk(hipMemcpyAsync(im.regs[diff_out].x, im.scratch, bytes, hipMemcpyDeviceToDevice, im.stream), "copy");
+    im.regs[diff_out].image = false;
+    if (diff_copy >= 0) { chk(hipMemcpyAsync(im.regs[diff_copy].x, im.scratch, bytes, hipMemcpyDeviceToDevice, im.stream), "copy"); im.regs[diff_copy].image = false; }
+  }
+  chk(hipStreamSynchronize(im.stream), "sync");
+}
+void CrtEngine::mul_add(size_t dst, size_t mul_src, size_t add_src, uint32_t f) { mul(dst, mul_src, f); add(dst, add_src); }
+void CrtEngine::square_mul_copy(size_t src, size_t dst_copy, uint32_t f) { square_mul(src, f); copy(dst_copy, src); }
+void CrtEngine::mul_copy(size_t dst, size_t src, size_t dst_copy, uint32_t f) { mul(dst, src, f); copy(dst_copy, dst); }
 
 void CrtEngine::set_u32(size_t reg, uint32_t a) {
   Impl& im = *im_;

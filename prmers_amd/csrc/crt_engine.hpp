@@ -38,6 +38,11 @@ class CrtEngine {
   void add(size_t dst, size_t src);
   void sub_reg(size_t dst, size_t src);
   void sub_u32(size_t reg, uint32_t a);
+  // the fused variants of engine.h:65-131 as the compositions its base class defines (one hidden scratch register)
+  void addsub(long sum_out, long sum_copy, long diff_out, long diff_copy, size_t a, size_t b);
+  void mul_add(size_t dst, size_t mul_src, size_t add_src, uint32_t f);
+  void square_mul_copy(size_t src, size_t dst_copy, uint32_t f);
+  void mul_copy(size_t dst, size_t src, size_t dst_copy, uint32_t f);
   bool equal(size_t a, size_t b);
   void set_digits(size_t reg, const uint64_t* d, size_t count);
   void get_digits(size_t reg, uint64_t* d, size_t count, bool canonical);

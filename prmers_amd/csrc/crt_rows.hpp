@@ -250,7 +250,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_crt[];
 template <bool INV>
 __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
   const Planes P = planes_of(smem_crt);
-  const uint32_t tid = threadIdx.x, logL = gr.logH1, L = 1u << logL, H2 = 1u << gr.logH2;
+  const uint32_t tid = threadIdx.x, logL = gr.logH1, H2 = 1u << gr.logH2;
   const uint32_t CA = kFastSlots >> logL, per_row = H2 / CA;
   const uint32_t row = blockIdx.x / per_row, col0 = (blockIdx.x - row * per_row) * CA;
   F61::C* z61 = Z61 + size_t(row) * gr.h; F31::C* z31 = Z31 + size_t(row) * gr.h;

@@ -120,6 +120,21 @@ def test_register_machine_copy_multiplicand_mul_add_sub_equal(p, odd, n):
             e.square_mul(3)
         with pytest.raises(Exception, match="multiplicand"):
             e.mul(0, 1)
+        # the fused variants (engine.h:65-131)
+        e.set_int(0, x); e.set_int(1, y)
+        e.addsub(2, 4, 0, 1)
+        assert e.get_int(2) == red(x + y) and e.get_int(4) == red(x + Mp - y)
+        e.addsub(0, 1, 0, 1)                            # in place: (x, y) <- (x + y, x - y)
+        assert e.get_int(0) == red(x + y) and e.get_int(1) == red(x + Mp - y)
+        e.set_int(0, x); e.set_int(1, y)
+        e.addsub_copy(2, 4, 5, 3, 0, 1)
+        assert e.get_int(5) == e.get_int(2) == red(x + y) and e.get_int(3) == e.get_int(4) == red(x + Mp - y)
+        e.set_multiplicand(3, 1); e.copy(2, 0); e.mul_add(2, 3, 0, 3)
+        assert e.get_int(2) == red(3 * x * y + x)
+        e.copy(2, 0); e.square_mul_copy(2, 4, 3)
+        assert e.get_int(2) == e.get_int(4) == red(3 * x * x)
+        e.copy(2, 0); e.mul_copy(2, 3, 5)
+        assert e.get_int(2) == e.get_int(5) == red(x * y)
         # (x y)^2 = x^2 y^2 through two different operation orders
         e.set_int(0, x); e.set_int(1, y)
         e.set_multiplicand(3, 1); e.copy(2, 0); e.mul(2, 3); e.square_mul(2)
