@@ -11,7 +11,7 @@ and always at exit -- plus an all_gather of the per-exponent results at exit.  R
 
 Command line (one process per GPU, rendezvous before any GPU call):
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
-      -m prmers_amd.launch --worktodo worktodo.txt [--per-gpu 2] [--results results.json.txt] [--max-iters N]
+      -m prmers_amd.launch --worktodo worktodo.txt [--per-gpu 2] [--results results.json.txt] [--max-iters N] [--fft crt:9]
 """
 import argparse
 import json
@@ -162,6 +162,8 @@ def main(argv=None):
     ap.add_argument("--max-iters", type=int, default=None, help="stop every entry after this many iterations (benchmarks)")
     ap.add_argument("--checklevel", type=int, default=0, help="Gerbicz-Li checks every this many block boundaries (0: the reference's automatic rule)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo")
+    ap.add_argument("--fft", default=None, help="transform spec handed to every engine: a plan (m2=..,c=..) or crt[:odd][:words=N] for the "
+                    "GF(M61^2) x GF(M31^2) family with a prime-factor axis (the reference's -fft)")
     ap.add_argument("--dry-run", action="store_true", help="print the shard of every rank and exit (no GPU, no process group)")
     args = ap.parse_args(argv)
 
@@ -194,7 +196,7 @@ def main(argv=None):
             sys.stderr.write("[status] %s\n" % json.dumps(st))
 
     try:
-        results, status = run_sharded(lines, lambda p: Engine(p, prp.REGISTERS, device=local_rank), device=device, max_iters=args.max_iters,
+        results, status = run_sharded(lines, lambda p: Engine(p, prp.REGISTERS, device=local_rank, plan=args.fft), device=device, max_iters=args.max_iters,
                                       checklevel=args.checklevel, log=log, per_gpu=args.per_gpu, on_status=on_status)
     finally:
         if dist.is_initialized():
