@@ -52,9 +52,13 @@
   X(40, "v_add_u32 + v_add_co_u32 alternating", asm volatile("v_add_u32 %0, %0, %2\n\tv_add_co_u32 %1, vcc, %1, %2" : "+v"(ra[i]), "+v"(rb[i]) : "v"(b) : "vcc");) \
   X(41, "v_add_u32 + v_mad_u64_u32 alternating", asm volatile("v_add_u32 %0, %0, %2\n\tv_mad_u64_u32 %1, vcc, %2, %3, %1" : "+v"(ra[i]), "+v"(rp[i]) : "v"(b), "v"(c) : "vcc");) \
   X(42, "v_add3_u32", asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(ra[i]) : "v"(b), "v"(c));) \
-  X(43, "v_sub_u32 sdwa-free e64 (sgpr src)", asm volatile("v_sub_u32 %0, %0, %1" : "+v"(ra[i]) : "s"(sb));)
+  X(43, "v_sub_u32 sdwa-free e64 (sgpr src)", asm volatile("v_sub_u32 %0, %0, %1" : "+v"(ra[i]) : "s"(sb));) \
+  X(44, "v_cmp_eq_u32_e32 -> vcc (VOPC)", asm volatile("v_cmp_eq_u32_e32 vcc, %0, %1" : : "v"(ra[i]), "v"(b) : "vcc");) \
+  X(45, "v_cmp_lt_u64_e32 -> vcc (VOPC)", asm volatile("v_cmp_lt_u64_e32 vcc, %0, %1" : : "v"(rp[i]), "v"(q) : "vcc");) \
+  X(46, "v_cmp_lt_u64_e32 vcc + v_cndmask_e32 (pair)", asm volatile("v_cmp_lt_u64_e32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %3, vcc" : "+v"(ra[i]) : "v"(rp[i]), "v"(q), "v"(b) : "vcc");) \
+  X(47, "v_cmp_lt_u64_e64 sgpr + v_cndmask_e64 (pair)", asm volatile("v_cmp_lt_u64 %1, %2, %3\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %4, %1" : "+v"(ra[i]), "=&s"(mask2) : "v"(rp[i]), "v"(q), "v"(b));)
 
-static const int kPer[] = {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,2,2,1,1,1,1,1,2,2,1,1};
+static const int kPer[] = {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,2,2,1,1,1,1,1,2,2,1,1,1,1,2,2};
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k_isa(uint32_t* out, int iters, uint32_t sb) {
