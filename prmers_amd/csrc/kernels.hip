@@ -55,10 +55,75 @@ __device__ __forceinline__ void digit_info(const DevPlan& pl, uint32_t sa, uint3
 // Elements of one transform sit at X[(base + i) * stride + col]; `groups` independent transforms of
 // length L (blocks x columns) are processed by the whole work-group.  root[e * rstep] = omega_L^e.
 // ---------------------------------------------------------------------------------------------
+// The same passes with one PLANE of a butterfly per thread (the two words of a pair go through identical, independent arithmetic):
+// twice the threads, half the instruction stream per wave.  Small tiles are latency-bound -- one or two waves per SIMD, so a launch
+// lasts as long as the dependent instruction stream of one wave (C2: 0.041 ms for three launches whose VALU work is 3 us) -- and the
+// way to shorten that stream is more threads with less work each, not wider butterflies (a radix-8 form made C2 35 % slower).
+template <bool INVERSE>
+__device__ __forceinline__ void lds_pow2_dft_planes(P2* X, uint32_t L, uint32_t logL, uint32_t nblocks, uint32_t ncols, uint32_t logcols,
+                                                    const uint64_t* __restrict__ root, uint32_t rootN, uint32_t rstep, uint32_t tid, uint32_t nthr) {
+  uint64_t* Xw = reinterpret_cast<uint64_t*>(X);   // element e, plane b at Xw[2 e + b]
+  const uint32_t n4 = logL / 2, has2 = logL & 1;
+  const uint32_t npass = n4 + has2;
+  for (uint32_t ps = 0; ps < npass; ++ps) {
+    const uint32_t pf = INVERSE ? (npass - 1 - ps) : ps;
+    if (pf < n4) {
+      const uint32_t loglen = logL - 2 * pf, len = 1u << loglen, q = len >> 2;
+      const uint32_t per = L >> 2;
+      const uint32_t total = per * nblocks * ncols * 2;
+      const uint32_t tstep = (L >> loglen) * rstep;
+      for (uint32_t idx2 = tid; idx2 < total; idx2 += nthr) {
+        const uint32_t plane = idx2 & 1, idx = idx2 >> 1;
+        const uint32_t col = idx & (ncols - 1), bi = idx >> logcols;
+        const uint32_t blk = bi >> (logL - 2), bj = bi & (per - 1);
+        const uint32_t sub = bj >> (loglen - 2), t = bj & (q - 1);
+        const uint32_t e0 = 2 * ((blk * L + sub * len + t) * ncols + col) + plane, es = 2 * q * ncols;
+        const uint32_t r1 = t * tstep;
+        const uint64_t x0 = Xw[e0], x1 = Xw[e0 + es], x2 = Xw[e0 + 2 * es], x3 = Xw[e0 + 3 * es];
+        if (!INVERSE) {
+          const uint64_t w1 = root[r1], w2 = root[2 * r1], w3 = root[3 * r1];
+          const uint64_t a = gf::add(x0, x2), b = gf::add(x1, x3), c = gf::sub(x0, x2), d = gf::mul_pow2(gf::sub(x1, x3), 48);
+          Xw[e0] = gf::add(a, b);
+          Xw[e0 + es] = gf::mul(gf::sub(a, b), w2);
+          Xw[e0 + 2 * es] = gf::mul(gf::add(c, d), w1);
+          Xw[e0 + 3 * es] = gf::mul(gf::sub(c, d), w3);
+        } else {
+          const uint64_t w1 = root[r1 ? rootN - r1 : 0], w2 = root[r1 ? rootN - 2 * r1 : 0], w3 = root[r1 ? rootN - 3 * r1 : 0];
+          const uint64_t y1 = gf::mul(x1, w2);
+          const uint64_t A = gf::add(x0, y1), B = gf::sub(x0, y1);
+          const uint64_t y2 = gf::mul(x2, w1), y3 = gf::mul(x3, w3);
+          const uint64_t Cc = gf::add(y2, y3), D = gf::mul_pow2(gf::sub(y3, y2), 48);
+          Xw[e0] = gf::add(A, Cc);
+          Xw[e0 + 2 * es] = gf::sub(A, Cc);
+          Xw[e0 + es] = gf::add(B, D);
+          Xw[e0 + 3 * es] = gf::sub(B, D);
+        }
+      }
+    } else {
+      const uint32_t per = L >> 1, total = per * nblocks * ncols * 2;
+      for (uint32_t idx2 = tid; idx2 < total; idx2 += nthr) {
+        const uint32_t plane = idx2 & 1, idx = idx2 >> 1;
+        const uint32_t col = idx & (ncols - 1), bi = idx >> logcols;
+        const uint32_t blk = bi >> (logL - 1), bj = bi & (per - 1);
+        const uint32_t e0 = 2 * ((blk * L + 2 * bj) * ncols + col) + plane;
+        const uint64_t u = Xw[e0], v = Xw[e0 + 2 * ncols];
+        Xw[e0] = gf::add(u, v);
+        Xw[e0 + 2 * ncols] = gf::sub(u, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <bool INVERSE>
 __device__ __forceinline__ void lds_pow2_dft(P2* X, uint32_t L, uint32_t logL, uint32_t nblocks, uint32_t ncols, uint32_t logcols,
                                              const uint64_t* __restrict__ root, uint32_t rootN, uint32_t rstep,
                                              uint64_t I4, uint32_t tid, uint32_t nthr) {
+  // small tiles: one plane per thread (see above); the work-group was sized for that by the launcher
+  if (nthr * 2 >= (L >> 2) * nblocks * ncols * 2 && nthr > (L >> 2) * nblocks * ncols) {
+    lds_pow2_dft_planes<INVERSE>(X, L, logL, nblocks, ncols, logcols, root, rootN, rstep, tid, nthr);
+    return;
+  }
   // forward: len = L, L/4, ... (radix-4) then a final radix-2 when log2 L is odd; inverse mirrors
   const uint32_t n4 = logL / 2, has2 = logL & 1;
   const uint32_t npass = n4 + has2;
@@ -494,23 +559,36 @@ static inline uint32_t block_for(size_t work) {
   return uint32_t(b);
 }
 
+// work-group size for a tile of `pairs` pairs: a quarter of it (one radix-4 butterfly per thread and pass), or half of it when the whole
+// launch has no more work-groups than the chip has CUs (latency-bound: one plane per thread, lds_pow2_dft_planes)
+static inline uint32_t block_for_small(const DevPlan& pl, size_t pairs) {
+  const size_t groups = size_t(pl.M1) * pl.M2 / (pairs ? pairs : 1);
+  const bool small = groups <= 256 && !(pl.tune & 8);   // at most one work-group per CU (with two per CU the classic form wins: n = 2^21, 0.066 vs 0.073 ms)
+  if (!small) return block_for(pairs / 4 ? pairs / 4 : 1);
+  // one pair per thread in the element-wise loops where the tile allows (C2: 0.0331 -> 0.0318 ms), else one plane per thread
+  const size_t want = (pl.tune & 16) ? pairs / 2 : pairs;
+  size_t b = 64;
+  while (b < 1024 && b < want) b <<= 1;
+  return uint32_t(b);
+}
+
 hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint64_t* W, hipStream_t s) {
   const size_t tile = size_t(pl.M1) * pl.C;
-  hipLaunchKernelGGL(k_front, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, digits, cbuf_in, W);
+  hipLaunchKernelGGL(k_front, dim3(pl.M2 / pl.C), dim3(block_for_small(pl, tile)), tile * 16, s, pl, digits, cbuf_in, W);
   return hipGetLastError();
 }
 hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
-  hipLaunchKernelGGL(k_middle, dim3(pl.M1), dim3(block_for(pl.M2 / 4 ? pl.M2 / 4 : 1)), size_t(pl.M2) * 16, s, pl, Win, Y, Wout, mode, sub);
+  hipLaunchKernelGGL(k_middle, dim3(pl.M1), dim3(block_for_small(pl, pl.M2)), size_t(pl.M2) * 16, s, pl, Win, Y, Wout, mode, sub);
   return hipGetLastError();
 }
 hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s) {
   const size_t tile = size_t(pl.M1) * pl.C;
-  hipLaunchKernelGGL(k_back<false>, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, W, digits, cbuf, a, BackExt());
+  hipLaunchKernelGGL(k_back<false>, dim3(pl.M2 / pl.C), dim3(block_for_small(pl, tile)), tile * 16, s, pl, W, digits, cbuf, a, BackExt());
   return hipGetLastError();
 }
 hipError_t launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s) {
   const size_t tile = size_t(pl.M1) * pl.C;
-  hipLaunchKernelGGL(k_back<true>, dim3(pl.M2 / pl.C), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, W, digits, cbuf, a, x);
+  hipLaunchKernelGGL(k_back<true>, dim3(pl.M2 / pl.C), dim3(block_for_small(pl, tile)), tile * 16, s, pl, W, digits, cbuf, a, x);
   return hipGetLastError();
 }
 hipError_t launch_linear(const DevPlan& pl, const LinArgs& la, hipStream_t s) {
