@@ -280,6 +280,15 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
   }
   __syncthreads();
 
+  // small tiles (one output element per thread): the three table words of its four-step twiddle are requested before the transform,
+  // whose passes hide their latency (latency-bound launches: see lds_pow2_dft_planes)
+  const bool one = tile <= nthr;
+  uint64_t pre_lo = 0, pre_hi = 0, pre_tb = 0;
+  if (one && tid < tile) {
+    const uint32_t pos = tid >> pl.logC, i2 = T * C + (tid & (C - 1));
+    const uint64_t ex = uint64_t(i2) * freq1(pl, pos);
+    pre_lo = pl.TWlo[ex & ((1u << pl.twh) - 1)]; pre_hi = pl.TWhi[ex >> pl.twh]; pre_tb = pl.TB[2 * i2];
+  }
   if (pl.r5 == 5) lds_radix5<false>(pl, X, C, tid, nthr);
   if (pl.logL1) lds_pow2_dft<false>(X, pl.L1, pl.logL1, pl.r5, C, pl.logC, pl.UT1, M1, pl.r5, pl.I4, tid, nthr);
 
@@ -288,9 +297,9 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
     const uint32_t pos = e >> pl.logC, c = e & (C - 1), i2 = T * C + c;
     const uint32_t k1 = freq1(pl, pos);
     const uint32_t ex = i2 * k1;   // i2 < M2, k1 < M1: below m, no reduction needed
-    const uint64_t tw = tw_lookup(pl, ex);
+    const uint64_t tw = one ? gf::mul(pre_lo, pre_hi) : tw_lookup(pl, ex);
     const P2 x = X[e];
-    const uint64_t twb = gf::mul(tw, pl.TB[2 * i2]);
+    const uint64_t twb = gf::mul(tw, one ? pre_tb : pl.TB[2 * i2]);
     W[size_t(pos) * pl.M2 + i2] = {gf::mul(x.a, twb), gf::mul(x.b, twb)};
   }
 }
@@ -310,16 +319,22 @@ __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __r
   // deferred small subtraction on a front image (digit 0 -> column 0, plane a of every row, weight 1)
   if (sub != 0 && tid == 0) X[0].a = gf::sub(X[0].a, uint64_t(sub));
   __syncthreads();
+  const uint32_t k1 = freq1(pl, row);
+  const bool one = M2 <= nthr;   // one element per thread: its twiddle words are requested before the transform (see k_front)
+  uint64_t pre_lo = 0, pre_hi = 0;
+  if (one && tid < M2 && mode != 2) {
+    const uint64_t ex = uint64_t(k1) + uint64_t(pl.M1) * (__brev(tid) >> (32 - pl.logM2));
+    pre_lo = pl.TWlo[ex & ((1u << pl.twh) - 1)]; pre_hi = pl.TWhi[ex >> pl.twh];
+  }
   lds_pow2_dft<false>(X, M2, pl.logM2, 1, 1, 0, pl.UT2, M2, 1, pl.I4, tid, nthr);
   if (mode == 2) {
     for (uint32_t e = tid; e < M2; e += nthr) out[e] = X[e];
     return;
   }
-  const uint32_t k1 = freq1(pl, row);
   const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * M2;
   for (uint32_t e = tid; e < M2; e += nthr) {
     const uint32_t k2 = __brev(e) >> (32 - pl.logM2);
-    const uint64_t rho = tw_lookup(pl, uint64_t(k1) + uint64_t(pl.M1) * k2);
+    const uint64_t rho = one ? gf::mul(pre_lo, pre_hi) : tw_lookup(pl, uint64_t(k1) + uint64_t(pl.M1) * k2);
     const P2 u = X[e];
     P2 r;
     if (mode == 0) {  // (u0 + u1 t)^2 mod (t^2 - rho), marin.cl:379-384
