@@ -5,14 +5,16 @@
 // (x, d), RBASE/RTMP = 3 and its multiplicand; check every `checklevel` blocks of B = floor(sqrt(p)).
 //
 // Caller-side files as the reference leaves them (include/mi355/caller_formats.h): -worktodo takes the first PRP= / Test= entry
-// and rotates the file when the test is complete; -ckpt DIR resumes from / saves version-2 checkpoints (every -backup N
-// iterations and at the end of a partial run); -proof POWER writes the residues a proof of that power needs under
+// and rotates the file when the test is complete; -ckpt DIR resumes from / saves version-2 checkpoints together with the
+// Gerbicz-Li rollback point (every -backup N iterations, at the end of a partial run, and on SIGINT / SIGTERM, which end the
+// run with exit code 0 like the reference's interrupt path, RunPrpOrLlMarin.cpp:296-309); -proof POWER writes the residues a proof of that power needs under
 // <p>/proof/; -json FILE appends the result line.
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/prp_cli.cpp -ldl -lgmp -o mi355_prp
 //   ./mi355_prp <p> | -worktodo FILE  [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER]
 //               [-json FILE] [-lib path/to/libmi355_engine.so]
 #include <cmath>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +25,9 @@
 #include "mi355/engine_hip.h"
 
 namespace fmt = mi355::formats;
+
+static volatile std::sig_atomic_t g_interrupted = 0;
+static void on_signal(int) { g_interrupted = 1; }
 
 static std::vector<uint32_t> residue_words(engine* eng, size_t reg, uint32_t p) {
   engine::digit d(eng, reg);
@@ -55,6 +60,8 @@ int main(int argc, char** argv) {
     p = entry.exponent; ll = entry.ll;
     std::printf("worktodo: %s\n", entry.raw.c_str());
   }
+  std::signal(SIGINT, on_signal);
+  std::signal(SIGTERM, on_signal);
   try {
     std::unique_ptr<engine> eng(new engine_hip(p, 8, 0, false, lib, fft));
     const size_t R0 = 0, R1 = 1, R2 = 2, R3 = 3, R4 = 4, R5 = 5, RBASE = 6, RTMP = 7;
@@ -74,15 +81,34 @@ int main(int argc, char** argv) {
     if (!ckpt.empty()) {
       int rc = fmt::load_checkpoint(ckpt, *eng, p, ll, ri, elapsed0);
       if (rc != 0) rc = fmt::load_checkpoint(ckpt + ".old", *eng, p, ll, ri, elapsed0);
-      if (rc == 0) { std::printf("Resuming from a checkpoint at iteration %u\n", ri); eng->set(RBASE, 3); eng->set_multiplicand(RTMP, RBASE); eng->copy(R4, R0); eng->copy(R5, R1); }
-      else ri = 0;
+      if (rc == 0) {
+        std::printf("Resuming from a checkpoint at iteration %u\n", ri);
+        eng->set(RBASE, 3); eng->set_multiplicand(RTMP, RBASE);
+        fmt::GerbiczState g;
+        if (!ll && fmt::load_gerbicz_state(ckpt, ri, g)) {   // R4 / R5 of the checkpoint are the state these counters name
+          itersave = g.itersave; jsave = g.jsave; checkpass = g.checkpass;
+        } else {                                              // no rollback point on file: roll back to the resumed state itself
+          eng->copy(R4, R0); eng->copy(R5, R1);
+          itersave = ri ? ri - 1 : 0; jsave = ri ? total - ri : total - 1;
+        }
+      } else ri = 0;
     }
+    auto checkpoint = [&](uint32_t at) {
+      fmt::save_checkpoint(ckpt, *eng, p, ll, at, elapsed0);
+      if (!ll) fmt::save_gerbicz_state(ckpt, at, fmt::GerbiczState{itersave, jsave, checkpass});
+    };
+    bool interrupted = false;
     std::unique_ptr<fmt::ProofPoints> proof;
     if (proof_power && !ll) proof.reset(new fmt::ProofPoints(p, proof_power));
     uint64_t last_iter = ri;
     for (uint64_t iter = ri, j = total - ri - 1; iter < total; ++iter, --j) {
+      last_iter = iter;   // iterations completed so far (a rollback moves it back too)
       if (maxiters && done >= maxiters) { complete = false; break; }
-      last_iter = iter + 1;
+      if (g_interrupted) {
+        complete = false; interrupted = true;
+        std::printf("\nInterrupted by user, state saved at iteration %llu j=%llu\n", (unsigned long long)iter, (unsigned long long)j);
+        break;
+      }
       eng->square_mul(R0);
       if (ll) eng->sub(R0, 2);
       ++done;
@@ -115,9 +141,10 @@ int main(int argc, char** argv) {
       }
       // proof residues (ProofManagerMarin::checkpointMarin, ProofManagerMarin.cpp:84-120) and periodic backups (:430-447)
       if (proof && proof->should_checkpoint(uint32_t(iter + 1))) proof->save(uint32_t(iter + 1), residue_words(eng.get(), R0, p));
-      if (!ckpt.empty() && backup && done % backup == 0) fmt::save_checkpoint(ckpt, *eng, p, ll, uint32_t(iter + 1), elapsed0);
+      if (!ckpt.empty() && backup && done % backup == 0 && iter + 1 < total) checkpoint(uint32_t(iter + 1));
     }
-    if (!ckpt.empty() && !complete) fmt::save_checkpoint(ckpt, *eng, p, ll, uint32_t(last_iter), elapsed0);   // iterations completed = the next iteration index
+    if (!ckpt.empty() && !complete) checkpoint(uint32_t(last_iter));   // iterations completed = the next iteration index
+    if (interrupted) return 0;
     engine::digit d(eng.get(), R0);
     const bool prime = ll ? (d.equal_to(0) || d.equal_to_Mp()) : d.equal_to(9);
     std::printf("M%u %s: %s  res64(raw)=%016llX  gerbicz_errors=%llu  n=%zu\n", p, ll ? "LL" : "PRP-3",

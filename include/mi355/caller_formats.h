@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include "../mi355_engine.h"
+#include <cstring>
 #include <filesystem>
 #include <fstream>
 #include <sstream>
@@ -137,6 +139,35 @@ int load_checkpoint(const std::string& path, const Engine& eng, uint32_t p, bool
   return eng.set_checkpoint(image) ? 0 : -2;
 }
 
+// ---- Gerbicz-Li rollback point next to a checkpoint (the reference keeps itersave / jsave in its backup manager and reloads them on
+//      a resume, RunPrpOrLlMarin.cpp:251-255).  <ckpt>.gl: u32 magic "GL3R", u32 iteration of the checkpoint it belongs to, u64 itersave,
+//      u64 jsave, u64 checkpass, u32 CRC-32 of the 32 bytes before it.  R4 / R5 (the state those counters name) travel in the checkpoint. ----
+constexpr uint32_t kGerbiczMagic = 0x474C3352u;
+struct GerbiczState { uint64_t itersave = 0, jsave = 0, checkpass = 0; };
+inline bool save_gerbicz_state(const std::string& ckpt_path, uint32_t iteration, const GerbiczState& g) {
+  unsigned char b[36];
+  std::memcpy(b, &kGerbiczMagic, 4); std::memcpy(b + 4, &iteration, 4);
+  std::memcpy(b + 8, &g.itersave, 8); std::memcpy(b + 16, &g.jsave, 8); std::memcpy(b + 24, &g.checkpass, 8);
+  const uint32_t crc = crc32_update(0, b, 32);
+  std::memcpy(b + 32, &crc, 4);
+  const std::string fresh = ckpt_path + ".gl.new";
+  { std::ofstream f(fresh, std::ios::binary); f.write(reinterpret_cast<const char*>(b), 36); if (!f.good()) return false; }
+  std::error_code ec;
+  std::filesystem::rename(fresh, ckpt_path + ".gl", ec);
+  return !ec;
+}
+inline bool load_gerbicz_state(const std::string& ckpt_path, uint32_t iteration, GerbiczState& g) {
+  std::ifstream f(ckpt_path + ".gl", std::ios::binary);
+  unsigned char b[37];
+  f.read(reinterpret_cast<char*>(b), 37);
+  if (f.gcount() != 36) return false;
+  uint32_t magic, it, crc;
+  std::memcpy(&magic, b, 4); std::memcpy(&it, b + 4, 4); std::memcpy(&crc, b + 32, 4);
+  if (magic != kGerbiczMagic || it != iteration || crc != crc32_update(0, b, 32)) return false;
+  std::memcpy(&g.itersave, b + 8, 8); std::memcpy(&g.jsave, b + 16, 8); std::memcpy(&g.checkpass, b + 24, 8);
+  return true;
+}
+
 // ---- worktodo.txt (WorktodoParser.cpp:98-104,331-348): PRP=[aid,]k,b,n,c[,...] / PRPDC= / Test=[aid,]p[,...] / DoubleCheck= ----
 struct WorkEntry { bool valid = false; bool ll = false; uint32_t exponent = 0; std::string aid, raw; };
 inline WorkEntry parse_worktodo_line(const std::string& line_in) {
@@ -201,7 +232,7 @@ inline bool rotate_worktodo(const std::string& path, const std::string& save_pat
 struct ResultInfo {
   uint32_t exponent = 0; bool ll = false, is_prime = false;
   std::string res64, res2048; unsigned gerbicz_errors = 0, fft_length = 0;
-  std::string program_version = "mi355-marin-hip 0.2", os_name = "Linux", os_arch = "x86_64", user, computer, aid, timestamp;
+  std::string program_version = "mi355-marin-hip " MI355_ENGINE_VERSION, os_name = "Linux", os_arch = "x86_64", user, computer, aid, timestamp;
   unsigned port = 8;
 };
 inline std::string json_escape(const std::string& s) {

@@ -25,6 +25,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define MI355_ENGINE_VERSION "0.3"   /* one version string: mi355_engine_version(), the result JSON of the callers */
 #define MI355_ENGINE_API __attribute__((visibility("default")))
 
 #ifdef __cplusplus

@@ -75,7 +75,7 @@ bool parse_crt_spec(const char* spec, CrtSpec& out) {
 
 extern "C" {
 
-const char* mi355_engine_version(void) { return "mi355-marin-hip 0.1 (gfx950)"; }
+const char* mi355_engine_version(void) { return "mi355-marin-hip " MI355_ENGINE_VERSION " (gfx950)"; }
 const char* mi355_engine_last_error(void) { return g_last_error.c_str(); }
 
 int mi355_engine_resolve_fft(uint32_t exponent, const char* fft_spec, char* output, size_t output_size) {
@@ -206,6 +206,11 @@ int mi355_crt_set_raw_digits(mi355_engine_handle h, size_t dst, const uint64_t* 
   return guarded([&] { if (!d || !crt(h)) throw std::runtime_error("set_raw_digits: needs a crt engine and a buffer"); crt(h)->set_digits(dst, d, count); });
 }
 size_t mi355_crt_transform_size(uint32_t exponent, uint32_t odd) { size_t r = 0; guarded([&] { r = mi355::crt_transform_size(exponent, odd); }); return r; }
+#if defined(MI355_PROBE)
+__attribute__((visibility("default"))) int mi355_probe(mi355_engine_handle h, int kind, int grid_mult, int extra_lds, int boost_pct, size_t iters, double* avg_ms, uint64_t* tl, size_t tl_words) {
+  return guarded([&] { eng(h)->probe(kind, grid_mult, extra_lds, boost_pct, iters, avg_ms, tl, tl_words); });
+}
+#endif
 size_t mi355_engine_algorithmic_bytes(mi355_engine_handle h) { size_t r = 0; guarded([&] { r = crt(h) ? crt(h)->algorithmic_bytes() : eng(h)->algorithmic_bytes(); }); return r; }
 
 }  // extern "C"

@@ -98,7 +98,6 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     auto from = [&](size_t grid) { return (!(dp_.tune & 4) && grid > slots) ? uint32_t(grid - size_t(slots) * pct / 100) : ~0u; };
     dp_.boost_rows = from(pl_.M1);
     dp_.boost_tiles = from(pl_.tiles());
-    dp_.boost_chain = from(2 * pl_.tiles());
   }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
   {
@@ -115,24 +114,6 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
       HIPCHK(v2_build_fourstep(dp_, f0_, f0_ + nt, f0_ + 2 * nt, f0_ + 2 * nt + pl_.M2, stream_));
       HIPCHK(hipStreamSynchronize(stream_));
       dp_.F0f = f0_; dp_.F0i = f0_ + nt; dp_.FBf = f0_ + 2 * nt; dp_.FBi = f0_ + 2 * nt + pl_.M2;
-    }
-    // fused back+front sweep: the residue stays in the work-buffer layout between squarings
-    // (measured at C3, same box: 0.176 ms/iter fused vs 0.164 unfused -- the fused work-group lives twice as long
-    // at 126 VGPRs and the sweeps are VALU-bound, so saving the digit round trip and one kernel boundary does
-    // not pay; kept selectable with MI355_FUSED=1, off by default)
-    const char* fz = std::getenv("MI355_FUSED");
-#if defined(MI355_EXPERIMENTAL)
-    fused_ = v2cols_ && fz && (fz[0] == '1' || fz[0] == '2');
-#else
-    if (fz && (fz[0] == '1' || fz[0] == '2'))
-      throw std::runtime_error("MI355_FUSED needs the experimental library (make -C prmers_amd/csrc exp; MI355_ENGINE_LIB=.../libmi355_engine_exp.so)");
-#endif
-    chained_ = fused_ && fz[0] == '2';   // back and front sweeps as two halves of one launch instead of one fused kernel
-    if (fused_) {
-      const size_t tiles = pl_.tiles();
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&cw_), tiles * pl_.M1 * 8));
-      HIPCHK(hipMalloc(reinterpret_cast<void**>(&flags_), (tiles + 16) * 4));
-      HIPCHK(hipMemsetAsync(flags_, 0, (tiles + 16) * 4, stream_));
     }
   }
 
@@ -152,8 +133,6 @@ Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (regs_) (void)hipFree(regs_);
-  if (cw_) (void)hipFree(cw_);
-  if (flags_) (void)hipFree(flags_);
   if (cbuf_) (void)hipFree(cbuf_);
   if (tables_) (void)hipFree(tables_);
   if (di_) (void)hipFree(di_);
@@ -173,37 +152,9 @@ void Engine::need_digits(size_t r, const char* op) const {
 void Engine::sync() {
   HIPCHK(hipSetDevice(device_));
   HIPCHK(hipStreamSynchronize(stream_));
-  check_device_error();
-}
-
-// the fused sweep reports a hand-off that never arrived (bounded poll) in a device word
-void Engine::check_device_error() {
-  if (!fused_) return;
-  uint32_t e = 0;
-  HIPCHK(hipMemcpy(&e, flags_ + pl_.tiles(), 4, hipMemcpyDeviceToHost));
-  if (e) throw std::runtime_error("fused sweep: inter-work-group carry hand-off timed out (results invalid)");
-}
-
-void Engine::ensure_front(size_t r) {
-  if (kind_[r] == kFront) return;
-  HIPCHK(v2_launch_front(dp_, digits(r), pending_carry_[r] ? cbuf(r) : nullptr, pending_sub_[r], work(), stream_));
-  swap_with_work(r);
-  kind_[r] = kFront;
-  pending_carry_[r] = 0; pending_sub_[r] = 0;
-}
-
-// front image -> digits: the exact inverse of the front sweep (scale M2 undoes the 1/m of the unweighting,
-// which expects a middle-sweep output); a pending subtraction stays pending
-void Engine::materialize(size_t r) {
-  if (kind_[r] != kFront) return;
-  HIPCHK(v2_launch_back(dp_, image(r), reinterpret_cast<uint32_t*>(work()), cbuf(r), 1, uint64_t(pl_.M2) % gf::P, stream_));
-  swap_with_work(r);
-  kind_[r] = kDigits;
-  pending_carry_[r] = 1;
 }
 
 void Engine::normalize(size_t r) {
-  materialize(r);
   if (kind_[r] != kDigits) return;
   if (pending_carry_[r]) {
     HIPCHK(launch_carry_fix(dp_, digits(r), cbuf(r), stream_));
@@ -473,7 +424,7 @@ void Engine::copy(size_t dst, size_t src) {
   if (dst == src) return;
   HIPCHK(hipSetDevice(device_));
   // the register is copied as it stands: digits with their pending run carries and small subtraction (no carry sweep),
-  // a front image with its deferred subtraction, a multiplicand image whole
+  // a multiplicand image whole
   const size_t bytes = (kind_[src] == kDigits) ? pl_.n * 4 : reg_bytes_;
   HIPCHK(hipMemcpyAsync(slot_[dst], slot_[src], bytes, hipMemcpyDeviceToDevice, stream_));
   if (kind_[src] == kDigits && pending_carry_[src])
@@ -485,18 +436,6 @@ void Engine::copy(size_t dst, size_t src) {
 
 void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
   if (ev) HIPCHK(hipEventRecord(ev[0], stream_));
-  if (fused_) {
-    // front image -> middle (in place) -> fused back+front (in place): two sweeps per squaring
-    ensure_front(r);
-    if (ev) HIPCHK(hipEventRecord(ev[1], stream_));
-    run_middle(image(r), nullptr, image(r), 0, pending_sub_[r]);
-    pending_sub_[r] = 0;
-    if (ev) HIPCHK(hipEventRecord(ev[2], stream_));
-    if (chained_) HIPCHK(v2_launch_back_then_front(dp_, image(r), reinterpret_cast<uint32_t*>(work()), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
-    else HIPCHK(v2_launch_back_front(dp_, image(r), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
-    if (ev) { HIPCHK(hipEventRecord(ev[3], stream_)); HIPCHK(hipEventRecord(ev[4], stream_)); }
-    return;
-  }
   run_front(r);
   if (ev) HIPCHK(hipEventRecord(ev[1], stream_));
   run_middle(work(), nullptr, work(), 0, 0);
@@ -526,12 +465,8 @@ void Engine::prepare(size_t dst, size_t src) {
   need_digits(src, "set_multiplicand");
   check_reg(dst);
   HIPCHK(hipSetDevice(device_));
-  if (kind_[src] == kFront) {
-    run_middle(image(src), nullptr, image(dst), 2, pending_sub_[src]);   // rows are read whole before they are written: in place is fine
-  } else {
-    run_front(src);
-    run_middle(work(), nullptr, image(dst), 2, 0);
-  }
+  run_front(src);
+  run_middle(work(), nullptr, image(dst), 2, 0);
   kind_[dst] = kImage;
   pending_carry_[dst] = 0; pending_sub_[dst] = 0;
 }
@@ -543,14 +478,6 @@ void Engine::mul(size_t dst, size_t src, uint32_t a) {
   if (dst == src) throw std::runtime_error("mul: dst and src must differ");
   if (a == 0) throw std::runtime_error("mul: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  if (fused_) {
-    ensure_front(dst);
-    run_middle(image(dst), image(src), image(dst), 1, pending_sub_[dst]);
-    pending_sub_[dst] = 0;
-    if (chained_) HIPCHK(v2_launch_back_then_front(dp_, image(dst), reinterpret_cast<uint32_t*>(work()), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
-    else HIPCHK(v2_launch_back_front(dp_, image(dst), cw_, flags_, ++epoch_, a, flags_ + pl_.tiles(), stream_));
-    return;
-  }
   run_front(dst);
   run_middle(work(), image(src), work(), 1, 0);
   run_back(dst, a);
@@ -569,7 +496,6 @@ void Engine::adopt_cbuf(size_t r, uint64_t* fresh) {
 
 void Engine::digits_ready(size_t r) {
   need_digits(r, "add/sub");
-  materialize(r);
   if (pending_sub_[r]) normalize(r);   // rare: a small subtraction not yet folded into a sweep
 }
 
@@ -642,7 +568,7 @@ void Engine::square_mul_copy(size_t src, size_t dst_copy, uint32_t a) {
   need_digits(src, "square_mul_copy"); check_reg(dst_copy);
   if (a == 0) throw std::runtime_error("square_mul_copy: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  if (fused_ || dst_copy == src) { square_mul(src, a); copy(dst_copy, src); return; }
+  if (dst_copy == src) { square_mul(src, a); copy(dst_copy, src); return; }
   run_front(src);
   run_middle(work(), nullptr, work(), 0, 0);
   back_ext(src, a, long(dst_copy), -1);
@@ -654,7 +580,7 @@ void Engine::mul_copy(size_t dst, size_t src, size_t dst_copy, uint32_t a) {
   if (dst == src || dst_copy == src) throw std::runtime_error("mul_copy: the multiplicand must differ from the outputs");
   if (a == 0) throw std::runtime_error("mul_copy: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  if (fused_ || dst_copy == dst) { mul(dst, src, a); copy(dst_copy, dst); return; }
+  if (dst_copy == dst) { mul(dst, src, a); copy(dst_copy, dst); return; }
   run_front(dst);
   run_middle(work(), image(src), work(), 1, 0);
   back_ext(dst, a, long(dst_copy), -1);
@@ -666,7 +592,6 @@ void Engine::mul_add(size_t dst, size_t mul_src, size_t add_src, uint32_t a) {
   if (dst == mul_src) throw std::runtime_error("mul_add: dst and mul_src must differ");
   if (a == 0) throw std::runtime_error("mul_add: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  if (fused_) { mul(dst, mul_src, a); add(dst, add_src); return; }
   if (add_src != dst) digits_ready(add_src);
   else if (kind_[dst] != kDigits || pending_sub_[dst]) normalize(dst);
   run_front(dst);   // reads digits(dst) (+ pending carries) and leaves them in place
@@ -757,14 +682,18 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
     const size_t per = 6;
     std::vector<hipEvent_t> ev(reps * per);
     for (auto& x : ev) HIPCHK(hipEventCreate(&x));
-    // cost of one event record: spacing of back-to-back records
+    // cost of one event record: spacing of back-to-back records on a batch of its own (its size does not depend on `iters`)
     double overhead = 0;
     {
-      for (size_t i = 0; i < reps * per; ++i) HIPCHK(hipEventRecord(ev[i], stream_));
+      constexpr size_t kBatch = 64, kSkip = 8;   // the first records carry the queue start-up
+      std::vector<hipEvent_t> oe(kBatch);
+      for (auto& x : oe) HIPCHK(hipEventCreate(&x));
+      for (size_t i = 0; i < kBatch; ++i) HIPCHK(hipEventRecord(oe[i], stream_));
       HIPCHK(hipStreamSynchronize(stream_));
       float t = 0;
-      HIPCHK(hipEventElapsedTime(&t, ev[per], ev[reps * per - 1]));   // skip the first records (queue start-up)
-      overhead = double(t) / double(reps * per - 1 - per);
+      HIPCHK(hipEventElapsedTime(&t, oe[kSkip], oe[kBatch - 1]));
+      overhead = double(t) / double(kBatch - 1 - kSkip);
+      for (auto& x : oe) HIPCHK(hipEventDestroy(x));
     }
     for (size_t i = 0; i < reps; ++i) {
       square_chain(r, a, &ev[i * per]);
@@ -780,12 +709,57 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
       }
     for (auto& x : ev) HIPCHK(hipEventDestroy(x));
     // which of the five slots hold a kernel on this path
-    const bool fix_now = !fused_ && !v2cols_ && pl_.C < 2;                        // k_carry_fix right after the back sweep
+    const bool fix_now = !v2cols_ && pl_.C < 2;                        // k_carry_fix right after the back sweep
     const bool sub_kernel = sub != 0 && !(v2cols_ && sub < (1u << 30));          // k_sub_small (else folded into the next front sweep)
     const bool launched[5] = {true, true, true, fix_now, sub_kernel};
     for (size_t k = 0; k < 5 && k < kcount; ++k) kernel_ms[k] = launched[k] ? std::max(0.0, kernel_ms[k] - overhead) : -1.0;
     if (kcount > 5) kernel_ms[5] = overhead;
   }
 }
+
+#if defined(MI355_PROBE)
+void Engine::probe(int kind, int grid_mult, int extra_lds, int boost_pct, size_t iters, double* avg_ms, uint64_t* tl, size_t tl_words) {
+  HIPCHK(hipSetDevice(device_));
+  if (!v2cols_ || !v2rows_) throw std::runtime_error("probe: needs the register-resident kernels");
+  if (grid_mult < 1 || kind < 0 || kind > 2) throw std::runtime_error("probe: bad arguments");
+  const size_t base = (kind == 1) ? pl_.M1 : pl_.tiles(), grid = base * size_t(grid_mult);
+  if (tl && tl_words < grid * 8) throw std::runtime_error("probe: timeline buffer too small");
+  DevPlan d = dp_;
+  d.probe = nullptr; d.probe_mod = uint32_t(base);
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_));
+    const size_t per_cu = (v2_lds_bytes() + size_t(extra_lds)) * 2 <= size_t(160) * 1024 ? 2 : 1;
+    const size_t slots = per_cu * size_t(prop.multiProcessorCount);
+    const uint32_t from = (boost_pct > 0 && grid > slots) ? uint32_t(grid - slots * size_t(boost_pct) / 100) : ~0u;
+    d.boost_rows = d.boost_tiles = from;
+  }
+  uint64_t* dtl = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&dtl), grid * 64));
+  HIPCHK(hipMemset(dtl, 0, grid * 64));
+  uint32_t* dout = reinterpret_cast<uint32_t*>(slot_[0]);   // register 0 is scratch here
+  auto launch = [&](const DevPlan& dd) { HIPCHK(v2_probe_launch(dd, kind, grid_mult, extra_lds, digits(1 % nregs_), kind == 2 ? cbuf(0) : nullptr, work(), dout, stream_)); };
+  for (int w = 0; w < 3; ++w) launch(d);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipStreamSynchronize(stream_));
+  HIPCHK(hipEventRecord(e0, stream_));
+  for (size_t i = 0; i < iters; ++i) launch(d);
+  HIPCHK(hipEventRecord(e1, stream_));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_ms) *avg_ms = double(ms) / double(iters ? iters : 1);
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  if (tl) {
+    d.probe = dtl;
+    launch(d);
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipMemcpy(tl, dtl, grid * 64, hipMemcpyDeviceToHost));
+  }
+  HIPCHK(hipFree(dtl));
+  HIPCHK(v2_configure());   // restore the LDS attributes
+}
+#endif
 
 }  // namespace mi355

@@ -61,20 +61,21 @@ class Engine {
   static const char* kernel_name(size_t k);
   void time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, double* total_ms, double* kernel_ms, size_t kcount);
   size_t algorithmic_bytes() const { return 48 * pl_.n; }
+#if defined(MI355_PROBE)
+  // diagnostics build only: `iters` timed launches of one sweep (kind 0 front, 1 rows, 2 back) over grid_mult x its grid with
+  // extra_lds bytes of padding LDS (forces fewer groups per CU), then one launch with the timeline probe on (8 words per group -> tl)
+  void probe(int kind, int grid_mult, int extra_lds, int boost_pct, size_t iters, double* avg_ms, uint64_t* tl, size_t tl_words);
+#endif
 
  private:
-  // kDigits: unweighted u32 digits (+ deferred run carries / subtraction); kImage: multiplicand;
-  // kFront: front-transformed residue (work-buffer layout) left by the fused back+front sweep
-  enum Kind : uint8_t { kDigits = 0, kImage = 1, kFront = 2 };
+  // kDigits: unweighted u32 digits (+ deferred run carries / subtraction); kImage: multiplicand
+  enum Kind : uint8_t { kDigits = 0, kImage = 1 };
   void check_reg(size_t r) const;
   void need_digits(size_t r, const char* op) const;
   uint32_t* digits(size_t r) { return reinterpret_cast<uint32_t*>(slot_[r]); }
   uint64_t* image(size_t r) { return reinterpret_cast<uint64_t*>(slot_[r]); }
   uint64_t* work() { return reinterpret_cast<uint64_t*>(slot_[nregs_]); }
   void swap_with_work(size_t r) { std::swap(slot_[r], slot_[nregs_]); }
-  void ensure_front(size_t r);       // kDigits -> kFront (fused mode)
-  void materialize(size_t r);        // kFront -> kDigits
-  void check_device_error();
   void read_values(size_t src, std::vector<uint64_t>& v);   // natural order, strongly carried digits
   void read_values_host(size_t src, std::vector<uint64_t>& v);   // the same through D2H + host carry (reference's way)
   uint32_t* canon_digits(size_t r, int slot);   // device: canonical digits of r in natural order (canon.hip), slot 0 / 1
@@ -84,7 +85,7 @@ class Engine {
   uint64_t* cbuf(size_t r) { return cb_[r]; }
   uint64_t* take_spare_cbuf();                      // carry-word buffers are handed around like the register slots
   void adopt_cbuf(size_t r, uint64_t* fresh);       // r's pending carries are now in `fresh`; its old buffer becomes spare
-  void digits_ready(size_t r);                      // r as a digit register for a run-wise kernel (front image materialised, small subtraction applied)
+  void digits_ready(size_t r);                      // r as a digit register for a run-wise kernel (small subtraction applied)
   void linear(long s1, long s2, long d1, long d2, size_t a, size_t b);
   void back_ext(size_t dst, uint32_t a, long copy_to, long add_src);
   void normalize(size_t r);          // apply deferred run carries / small subtraction
@@ -101,10 +102,6 @@ class Engine {
   size_t nregs_ = 0, reg_bytes_ = 0;
   unsigned char* regs_ = nullptr;            // (reg_count + 1) slots of 8n bytes; the extra one is the work buffer
   std::vector<unsigned char*> slot_;          // slot_[r]: storage of register r; slot_[reg_count]: work buffer (swappable)
-  uint64_t* cw_ = nullptr;                    // fused sweep: carry words between work-groups
-  uint32_t* flags_ = nullptr;                 // fused sweep: per-work-group epoch flags (+ error word at the end)
-  uint32_t epoch_ = 0;
-  bool fused_ = false, chained_ = false;
   uint64_t* cbuf_ = nullptr;                  // reg_count + 4 buffers of runs() carry words
   std::vector<uint64_t*> cb_, cb_spare_;      // cb_[r]: the buffer register r uses now
   void* tables_ = nullptr;

@@ -15,7 +15,11 @@ struct DevPlan {
   uint64_t W5c[4];   // 5-point DFT constants {beta, k1, k2-k1, k1+k2} (kernels.hip dft5)
   const uint64_t *F0f, *F0i, *FBf, *FBi;   // four-step chain starts [tile][thread] and ratios [column] of the v2 column kernels
   const uint32_t* DI;   // digit-info words of the v2 column kernels: [tile][thread] 16 x (width - q, wrap), or null
-  uint32_t boost_rows, boost_tiles, boost_chain;   // first block index of the last half round of the row / column launches (or ~0u)
+  uint32_t boost_rows, boost_tiles;   // first block index of the last half round of the row / column launches (or ~0u)
+#if defined(MI355_PROBE)
+  uint64_t* probe;        // timeline probe (tools/probe.py, libmi355_engine_probe.so only): 8 words per work-group, or null
+  uint32_t probe_mod;     // blockIdx.x is taken modulo this (launches of several rounds over the same tiles)
+#endif
   uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs; bit 2: no issue-priority boost of the last half round
 };
 
@@ -59,11 +63,11 @@ hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s);
-// fused back + front sweep, in place on a work buffer / front image (cw: [tiles][M1] carry words, flags: [tiles])
-// back sweep then front sweep of every tile in one launch (2 x tiles blocks; scratch: 4n bytes of digits)
-hipError_t v2_launch_back_then_front(const DevPlan& pl, uint64_t* W, uint32_t* scratch, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a,
-                                     uint32_t* err, hipStream_t s);
-hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s);
+#if defined(MI355_PROBE)
+size_t v2_lds_bytes();
+// one launch of sweep `kind` (0 front, 1 rows, 2 back) over grid_mult x the normal grid with extra_lds bytes of padding LDS
+hipError_t v2_probe_launch(const DevPlan& pl, int kind, int grid_mult, int extra_lds, const uint32_t* digits, uint64_t* cbuf, uint64_t* W, uint32_t* dout, hipStream_t s);
+#endif
 
 // device-side canonical form (canon.hip): strong carry with wrap-around into natural order, compare, scatter
 size_t canon_scratch_words(const DevPlan& pl);

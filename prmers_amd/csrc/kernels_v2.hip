@@ -132,17 +132,39 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#if defined(MI355_PROBE)
+// timeline probe: thread 0 of every work-group records {realtime0, realtime1, shader clock0, clock1, HW_ID, XCC_ID, mid realtime}
+#define PROBE_BEGIN(pl)                                                                             \
+  uint64_t pb_r0_ = 0, pb_c0_ = 0, pb_rm_ = 0;                                                      \
+  if (pl.probe) { pb_r0_ = __builtin_amdgcn_s_memrealtime(); pb_c0_ = __builtin_amdgcn_s_memtime(); }
+#define PROBE_MID(pl) if (pl.probe) pb_rm_ = __builtin_amdgcn_s_memrealtime();
+#define PROBE_END(pl)                                                                               \
+  if (pl.probe && threadIdx.x == 0) {                                                               \
+    uint64_t* o_ = pl.probe + size_t(blockIdx.x) * 8;                                               \
+    o_[0] = pb_r0_; o_[1] = __builtin_amdgcn_s_memrealtime(); o_[2] = pb_c0_; o_[3] = __builtin_amdgcn_s_memtime(); \
+    o_[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); o_[6] = pb_rm_; \
+  }
+#define PROBE_BLOCK(pl) (pl.probe_mod ? blockIdx.x % pl.probe_mod : blockIdx.x)
+#define PROBE_GRID(pl) (pl.probe_mod ? pl.probe_mod : gridDim.x)
+#else
+#define PROBE_BEGIN(pl)
+#define PROBE_MID(pl)
+#define PROBE_END(pl)
+#define PROBE_BLOCK(pl) blockIdx.x
+#define PROBE_GRID(pl) gridDim.x
+#endif
+
 // exchange helpers: barrier, write 8, barrier, read 8
 #define EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)                      \
-  __syncthreads();                                                 \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) X[phys((t) * 8 + r_)] = x[r_]; \
-  __syncthreads();                                                 \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) x[j_] = X[phys(j_ * 512 + (t))];
 
 #define EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)                      \
-  __syncthreads();                                                 \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) X[phys(j_ * 512 + (t))] = x[j_]; \
-  __syncthreads();                                                 \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) x[r_] = X[phys((t) * 8 + r_)];
 
 // ---------------------------------------------------------------------------------------------
@@ -164,7 +186,8 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   const uint32_t h = (H == 2) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0u;
   if (H == 1) boost_if_late(pl.boost_rows);
   P2* X = reinterpret_cast<P2*>(smem_v2) + h * kLdsSlots;
-  const uint32_t t = threadIdx.x & 511, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7), row = blockIdx.x;
+  const uint32_t t = threadIdx.x & 511, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7), row = PROBE_BLOCK(pl);
+  PROBE_BEGIN(pl)
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * (4096 * H);
   P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * (4096 * H) + h * 4096;
   P2 x[8];
@@ -208,10 +231,10 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false, 1>(x);
   seam64<false, true>(x, wave);
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int k = 0; k < 8; ++k) X[phys(wave * 512 + k * 64 + lane)] = x[k];
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = X[phys(j * 512 + t)];
   dft8p<false, 2>(x);   // mode 2 stores them for a later multiplication, the pointwise stage multiplies
@@ -222,6 +245,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
     return;
   }
 
+  PROBE_MID(pl)
   // ---- pointwise: reg k4 holds X[kb + 512 k4]; rho = omega_m^(k1row + M1 k) = rho0 * omega_8^k4 ----
   {
     const uint64_t rho0 = gf::mul(rho_lo, rho_hi);
@@ -251,10 +275,10 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
 
   // ---- inverse (mirror) ----
   dft8p<true>(x);
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int j = 0; j < 8; ++j) X[phys(j * 512 + t)] = x[j];
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int k = 0; k < 8; ++k) x[k] = X[phys(wave * 512 + k * 64 + lane)];
   seam64<true>(x, wave);
@@ -292,6 +316,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
+  PROBE_END(pl)
 }
 
 // previous run (in digit order) of run (T, i1); see kernels.hip
@@ -451,10 +476,10 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   {
     // lane = (k1 C + c) 8 + k2  ->  slot offset (k1 | k2 | c)
     const uint32_t off = ((lane >> (3 + LC)) << (3 + LC)) | ((lane & 7) << LC) | ((lane >> 3) & (C - 1));
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < 8; ++k) X[phys(wave * 512 + k * 64 + off)] = x[k];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = X[phys(j * 512 + t)];
   }
@@ -510,10 +535,10 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   dft8p<true>(x);
   {
     const uint32_t off = ((lane >> (3 + LC)) << (3 + LC)) | ((lane & 7) << LC) | ((lane >> 3) & (C - 1));
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < 8; ++j) X[phys(j * 512 + t)] = x[j];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = X[phys(wave * 512 + k * 64 + off)];
   }
@@ -592,8 +617,9 @@ __global__ void __launch_bounds__(512, 4) k1_cols(DevPlan pl, const uint32_t* __
   // tile order: with two pairs per run (R = 4) four tiles share each 128-byte line of the work buffer, and keeping
   // them on one XCD lets its L2 merge the 32-byte pieces (n = 2^24: front sweep 97 -> 89 us); with wider runs the
   // plain order is as good or better (C3: 43.2 vs 44.9 us)
-  const uint32_t T = (R == 4) ? tile_of_block(pl, blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint32_t T = (R == 4) ? tile_of_block(pl, PROBE_BLOCK(pl), PROBE_GRID(pl)) : PROBE_BLOCK(pl);
   boost_if_late(pl.boost_tiles);
+  PROBE_BEGIN(pl)
   uint32_t dg[R][16 / R];
   const uint32_t di = pl.DI[size_t(T) * 512 + t];
 #pragma unroll
@@ -603,6 +629,7 @@ __global__ void __launch_bounds__(512, 4) k1_cols(DevPlan pl, const uint32_t* __
     if (cbuf_in) apply_carry_in<16 / R>(pl, di, d1, carry_in_of(pl, cbuf_in, T, i1), dg[d1]);
   }
   front_tile<R>(pl, X, T, t, lane, wave, dg, di, sub, Wout);
+  PROBE_END(pl)
 }
 
 // back sweep: work buffer -> digits + one carry word per run
@@ -610,8 +637,9 @@ template <int R>
 __global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
                                                   uint64_t* __restrict__ cbuf, uint32_t a, uint64_t scale) {
   P2* X = reinterpret_cast<P2*>(smem_v2);
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, blockIdx.x, gridDim.x);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), T = tile_of_block(pl, PROBE_BLOCK(pl), PROBE_GRID(pl));
   boost_if_late(pl.boost_tiles);
+  PROBE_BEGIN(pl)
   uint32_t dg[R][16 / R];
   uint64_t cout[R], zero[R];
 #pragma unroll
@@ -623,6 +651,7 @@ __global__ void __launch_bounds__(512, 4) k3_cols(DevPlan pl, const uint64_t* __
     store_run<R>(digits, T, i1, dg[d1]);
     cbuf[size_t(T) * (512 * R) + i1] = cout[d1];
   }
+  PROBE_END(pl)
 }
 
 // back sweep with extras (kernels.hpp BackExt): a second destination register and / or an addend in the carry chain
@@ -656,156 +685,7 @@ __global__ void __launch_bounds__(512, 4) k3_cols_ext(DevPlan pl, const uint64_t
   }
 }
 
-#if defined(MI355_EXPERIMENTAL)   // not in the shipped library: make -C prmers_amd/csrc exp
-// ---------------------------------------------------------------------------------------------
-// Fused back + front sweep (work buffer -> work buffer, in place): the residue never goes to memory as
-// digits between two squarings and one of the three kernel boundaries per squaring disappears.  One tile
-// per work-group:  back(T) [carry-in 0]  ->  publish the R carry-out words per thread (write-through
-// stores, then one flag store per work-group)  ->  wait for tile T-1's flag, fetch its carry words, fold
-// them into the first digits of the runs  ->  front(T).  Tile T-1 belongs to a work-group dispatched
-// earlier (block b - 8 under the XCD-contiguous tile order), which published long before this one finished
-// its own back phase; only the 8 work-groups that start an XCD chunk wait for a late one (the number is
-// cyclic: tile 0 continues the last tile).  No work-group waits before it has published, so the chain cannot
-// deadlock under in-order dispatch; the poll is bounded anyway and reports through *err.  Hand-off
-// protocol: cdna_hip_programming.md Guideline 16, "sc1 stores + drained flag" row (flag = epoch of this launch).
-// ---------------------------------------------------------------------------------------------
-template <int R>
-__global__ void __launch_bounds__(512, 4) k31_cols(DevPlan pl, uint64_t* __restrict__ Wbuf, uint64_t* __restrict__ cw,
-                                                   uint32_t* __restrict__ flags, uint32_t epoch, uint32_t a, uint32_t* __restrict__ err) {
-  P2* X = reinterpret_cast<P2*>(smem_v2);
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const uint32_t NT = gridDim.x, T = tile_of_block(pl, blockIdx.x, NT);
-  constexpr uint32_t M1 = 512 * R;
-  const uint32_t di = pl.DI[size_t(T) * 512 + t];
-  uint32_t dg[R][16 / R];
-  uint64_t cout[R], zero[R];
-#pragma unroll
-  for (int d1 = 0; d1 < R; ++d1) zero[d1] = 0;
-  back_tile<R>(pl, X, T, t, lane, wave, Wbuf, a, 1, zero, di, dg, cout);
-  // publish the carry words leaving this tile (they enter tile T + 1, or the next row of tile 0)
-#pragma unroll
-  for (int d1 = 0; d1 < R; ++d1)
-    __hip_atomic_store(cw + size_t(T) * M1 + 512 * d1 + t, cout[d1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const uint32_t pT = T ? T - 1 : NT - 1;
-  if (t == 0) {
-    __hip_atomic_store(flags + T, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t ok = 0;
-    for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-      if (__hip_atomic_load(flags + pT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = 1; break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    if (!ok) atomicOr(err, 1u);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int d1 = 0; d1 < R; ++d1) {
-    const uint32_t i1 = 512 * d1 + t;
-    const uint32_t pi = T ? i1 : (i1 ? i1 - 1 : M1 - 1);
-    const uint64_t cin = __hip_atomic_load(cw + size_t(pT) * M1 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    apply_carry_in<16 / R>(pl, di, d1, cin, dg[d1]);
-  }
-  front_tile<R>(pl, X, T, t, lane, wave, dg, di, 0, Wbuf);
-}
-
 }  // namespace v2
-
-namespace v2 {
-// Agent-coherent (write-through / cache-bypassing) 16-byte accesses for in-launch hand-offs, per
-// cdna_hip_programming.md Guideline 16 R1: aux = 16 is the sc1 bit on gfx950.
-typedef int hx_v4i __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t hx_rsrc_t;
-__device__ __forceinline__ hx_rsrc_t hx_rsrc(void* base, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(base, /*stride*/ 0, int(bytes), 0x00020000);
-}
-__device__ __forceinline__ void hx_store16_sc1(hx_rsrc_t rsrc, uint32_t byte_off, uint4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(hx_v4i{int(v.x), int(v.y), int(v.z), int(v.w)}, rsrc, int(byte_off), 0, 16);
-}
-__device__ __forceinline__ uint4 hx_load16_sc1(hx_rsrc_t rsrc, uint32_t byte_off) {
-  const hx_v4i r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(byte_off), 0, 16);
-  return make_uint4(uint32_t(r.x), uint32_t(r.y), uint32_t(r.z), uint32_t(r.w));
-}
-
-// ---------------------------------------------------------------------------------------------
-// Chained back -> front sweep in ONE launch (experimental, MI355_FUSED=2): blocks [0, NT) are the back sweep of
-// tile tile_of_block(b) (work buffer -> digits in a scratch area + carry words), blocks [NT, 2 NT) the front
-// sweep of tile tile_of_block(b - NT) (scratch digits + carry-in -> work buffer, in place).  A front block
-// waits for the flags of its own tile and of the previous one; both belong to back blocks, and every back
-// block has been dispatched before the first front block is (one launch, in-order dispatch), so the wait
-// always resolves.  Unlike the fused kernel above the two halves keep their own register budgets and the
-// front blocks fill the drain of the back ones.  Hand-off (cdna_hip_programming.md Guideline 16 R1): sc1
-// (write-through) stores of the digits and carry words -> every wave drains its stores -> barrier -> flag;
-// the consumer polls the flags, then reads the handed-off words with sc1 loads only.
-// ---------------------------------------------------------------------------------------------
-template <int R>
-__global__ void __launch_bounds__(512, 4) k3k1_cols(DevPlan pl, uint64_t* __restrict__ Wbuf, uint32_t* __restrict__ scratch,
-                                                    uint64_t* __restrict__ cw, uint32_t* __restrict__ flags, uint32_t epoch, uint32_t a,
-                                                    uint32_t* __restrict__ err) {
-  P2* X = reinterpret_cast<P2*>(smem_v2);
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const uint32_t NT = gridDim.x >> 1;
-  constexpr uint32_t M1 = 512 * R;
-  uint32_t dg[R][16 / R];
-  if (blockIdx.x < NT) {   // ---- back sweep of one tile ----
-    const uint32_t T = tile_of_block(pl, blockIdx.x, NT);
-    const uint32_t di = pl.DI[size_t(T) * 512 + t];
-    uint64_t cout[R], zero[R];
-#pragma unroll
-    for (int d1 = 0; d1 < R; ++d1) zero[d1] = 0;
-    back_tile<R>(pl, X, T, t, lane, wave, Wbuf, a, 1, zero, di, dg, cout);
-    // write-through (sc1) stores of the handed-off digits and carry words: no release fence needed
-    const hx_rsrc_t rs = hx_rsrc(scratch, pl.n * 4u);
-    constexpr int Q = 4 / R;   // uint4 per run
-#pragma unroll
-    for (int d1 = 0; d1 < R; ++d1) {
-      const uint32_t i1 = 512 * d1 + t;
-#pragma unroll
-      for (int q = 0; q < Q; ++q)
-        hx_store16_sc1(rs, uint32_t(((size_t(T) * M1 + i1) * Q + q) * 16), make_uint4(dg[d1][4 * q], dg[d1][4 * q + 1], dg[d1][4 * q + 2], dg[d1][4 * q + 3]));
-      __hip_atomic_store(cw + size_t(T) * M1 + i1, cout[d1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) __hip_atomic_store(flags + T, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  // ---- front sweep of one tile ----
-  const uint32_t bf = blockIdx.x - NT;
-  const uint32_t T = tile_of_block(pl, bf, NT), pT = T ? T - 1 : NT - 1;
-  if (blockIdx.x >= pl.boost_chain) __builtin_amdgcn_s_setprio(3);
-  if (t == 0) {
-    uint32_t ok = 0;
-    for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-      if (__hip_atomic_load(flags + T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch &&
-          __hip_atomic_load(flags + pT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = 1; break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    if (!ok) atomicOr(err, 1u);
-  }
-  __syncthreads();
-  const uint32_t di = pl.DI[size_t(T) * 512 + t];
-  const hx_rsrc_t rs = hx_rsrc(scratch, pl.n * 4u);
-  constexpr int Q = 4 / R;
-#pragma unroll
-  for (int d1 = 0; d1 < R; ++d1) {
-    const uint32_t i1 = 512 * d1 + t;
-    const uint32_t pi = T ? i1 : (i1 ? i1 - 1 : M1 - 1);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {   // every load of handed-off data is sc1 (cache-bypassing)
-      const uint4 v = hx_load16_sc1(rs, uint32_t(((size_t(T) * M1 + i1) * Q + q) * 16));
-      dg[d1][4 * q] = v.x; dg[d1][4 * q + 1] = v.y; dg[d1][4 * q + 2] = v.z; dg[d1][4 * q + 3] = v.w;
-    }
-    const uint64_t cin = __hip_atomic_load(cw + size_t(pT) * M1 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    apply_carry_in<16 / R>(pl, di, d1, cin, dg[d1]);
-  }
-  front_tile<R>(pl, X, T, t, lane, wave, dg, di, 0, Wbuf);
-}
-
-}  // namespace v2
-#else
-}  // namespace v2
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // Columns of M1 = 1280 = 5 x 256 (n = 5 * 2^21: BASELINE configs[3] on the Goldilocks path), C = 4 pairs per run: one tile
@@ -1141,10 +1021,6 @@ hipError_t v2_configure() {
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v5::k1_cols5, v5::kLdsBytes) MI355_SET_LDS(v5::k3_cols5<false>, v5::kLdsBytes) MI355_SET_LDS(v5::k3_cols5<true>, v5::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols_ext<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols_ext<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols_ext<4>, v2::kLdsBytes)
-#if defined(MI355_EXPERIMENTAL)
-  MI355_SET_LDS(v2::k3k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3k1_cols<4>, v2::kLdsBytes)
-  MI355_SET_LDS(v2::k31_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<4>, v2::kLdsBytes)
-#endif
   return hipSuccess;
 }
 #undef MI355_SET_LDS
@@ -1197,30 +1073,31 @@ hipError_t v2_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* di
   }
   return hipGetLastError();
 }
-#if defined(MI355_EXPERIMENTAL)
-hipError_t v2_launch_back_then_front(const DevPlan& pl, uint64_t* W, uint32_t* scratch, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a,
-                                     uint32_t* err, hipStream_t s) {
-  const dim3 grid(2 * (pl.M2 / pl.C)), block(512);
-  switch (pl.M1) {
-    case 512: hipLaunchKernelGGL(v2::k3k1_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, scratch, cw, flags, epoch, a, err); break;
-    case 1024: hipLaunchKernelGGL(v2::k3k1_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, scratch, cw, flags, epoch, a, err); break;
-    default: hipLaunchKernelGGL(v2::k3k1_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, scratch, cw, flags, epoch, a, err); break;
-  }
-  return hipGetLastError();
-}
-hipError_t v2_launch_back_front(const DevPlan& pl, uint64_t* W, uint64_t* cw, uint32_t* flags, uint32_t epoch, uint32_t a, uint32_t* err, hipStream_t s) {
-  const dim3 grid(pl.M2 / pl.C), block(512);
-  switch (pl.M1) {
-    case 512: hipLaunchKernelGGL(v2::k31_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, cw, flags, epoch, a, err); break;
-    case 1024: hipLaunchKernelGGL(v2::k31_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, cw, flags, epoch, a, err); break;
-    default: hipLaunchKernelGGL(v2::k31_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, cw, flags, epoch, a, err); break;
-  }
-  return hipGetLastError();
-}
 
-#else
-hipError_t v2_launch_back_then_front(const DevPlan&, uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t, uint32_t, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
-hipError_t v2_launch_back_front(const DevPlan&, uint64_t*, uint64_t*, uint32_t*, uint32_t, uint32_t, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+#if defined(MI355_PROBE)
+size_t v2_lds_bytes() { return v2::kLdsBytes; }
+hipError_t v2_probe_launch(const DevPlan& pl, int kind, int grid_mult, int extra_lds, const uint32_t* digits, uint64_t* cbuf, uint64_t* W, uint32_t* dout, hipStream_t s) {
+  const size_t lds = v2::kLdsBytes + size_t(extra_lds);
+  if (kind == 1) {
+    if (pl.M2 != 4096) return hipErrorNotSupported;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((v2::k2_rows4096<0, 1>), dim3(pl.M1 * grid_mult), dim3(512), lds, s, pl, W, nullptr, W, 0u);
+    return hipGetLastError();
+  }
+  if (pl.M1 != 1024) return hipErrorNotSupported;
+  const dim3 grid((pl.M2 / pl.C) * grid_mult), block(512);
+  if (kind == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k1_cols<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(v2::k1_cols<2>, grid, block, lds, s, pl, digits, cbuf, 0u, W);
+  } else {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k3_cols<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(v2::k3_cols<2>, grid, block, lds, s, pl, W, dout, cbuf, 1u, uint64_t(1));
+  }
+  return hipGetLastError();
+}
 #endif
 
 }  // namespace mi355

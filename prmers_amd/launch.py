@@ -17,6 +17,7 @@ import argparse
 import json
 import math
 import os
+import signal
 import sys
 import threading
 
@@ -61,15 +62,21 @@ class StatusReducer:
 
 
 def run_sharded(worktodo_lines, make_engine, device="cpu", max_iters=None, checklevel=0, log=None, per_gpu=1,
-                sync_checks="auto", on_status=None, **run_kwargs):
+                sync_checks="auto", on_status=None, should_stop=None, ckpt_dir=None, backup_interval_s=None, **run_kwargs):
     """Each rank runs its share of the worktodo (line i -> rank i mod world) with make_engine(exponent) -> engine;
     returns (results_of_all_ranks, status) on every rank.
 
     status["all_ok"] is 1 only if every rank finished every entry without an exception and without a failed
-    Gerbicz-Li check; a rank that fails still takes part in every reduction, so nobody hangs.
+    Gerbicz-Li check.  The number of reductions a rank issues never depends on what happens to it: at check boundaries
+    it reduces once per FIRST visit of a boundary (a failed check rolls the entry back and meets the same boundaries
+    again: those visits do not reduce), and an entry that ends early -- exception, interrupt -- issues the reductions it
+    still owes before the rank moves on, so the collectives of all ranks stay matched.
     per_gpu > 1 runs that many entries of the rank concurrently (threads, one engine and stream each).
-    sync_checks: True / False / "auto" (reduce at check boundaries when every rank has the same number of them and
-    per_gpu == 1); on_status(status) is called on every rank after each reduction."""
+    sync_checks: True / False / "auto" (reduce at check boundaries when every rank has the same number of them,
+    per_gpu == 1 and no checkpoint directory is in play: a resumed entry has fewer boundaries left than a fresh one);
+    on_status(status) is called on every rank after each reduction.
+    should_stop(): polled by every entry before each iteration (SIGINT / SIGTERM in main): the entry checkpoints into
+    ckpt_dir and returns, the rank skips its remaining entries, and the launcher still exits through the reductions."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     entries = [e for e in (prp.parse_worktodo_line(l) for l in worktodo_lines) if e]
@@ -79,32 +86,45 @@ def run_sharded(worktodo_lines, make_engine, device="cpu", max_iters=None, check
     # boundary reductions only when every rank will reach the same number of them (else at exit only)
     per_rank_checks = [sum(check_boundaries(entries[r::world], checklevel)) for r in range(world)]
     lockstep = (sync_checks is True) or (sync_checks == "auto" and per_gpu == 1 and max_iters is None and checklevel > 0 and
-                                         world > 1 and len(set(per_rank_checks)) == 1)
+                                         ckpt_dir is None and world > 1 and len(set(per_rank_checks)) == 1)
     state = {"ok": 1, "errors": 0, "iters": 0}
     state_lock = threading.Lock()
     results = []
 
     def one(mode, p):
         base_iters = [0]
+        owed = check_boundaries([(mode, p)], checklevel)[0] if lockstep else 0   # boundary reductions of this entry
+        visited = [0]                                                             # highest boundary already reduced
+
+        def reduce_now():
+            with state_lock:
+                snap = dict(state)
+            st = reducer.reduce(snap["ok"], snap["errors"], snap["iters"])
+            if on_status:
+                on_status(st)
 
         def on_check(passed, it):
+            nonlocal owed
             with state_lock:
                 if not passed:
                     state["ok"] = 0
                     state["errors"] += 1
-                state["iters"] += it - base_iters[0]
-                base_iters[0] = it
-                snap = dict(state)
-            if lockstep:
-                st = reducer.reduce(snap["ok"], snap["errors"], snap["iters"])
-                if on_status:
-                    on_status(st)
+                state["iters"] += max(it - base_iters[0], 0)
+                base_iters[0] = max(it, base_iters[0])
+            if lockstep and owed > 0 and it > visited[0]:
+                visited[0] = it
+                owed -= 1
+                reduce_now()
 
         r = None
         try:
             eng = make_engine(p)
             try:
-                r = prp.run_prp_or_ll(eng, p, mode, max_iters=max_iters, checklevel=checklevel, log=log, on_check=on_check, **run_kwargs)
+                kw = dict(run_kwargs)
+                if ckpt_dir is not None:
+                    kw.update(ckpt_path=prp.checkpoint_name(p, mode, ckpt_dir), backup_interval_s=backup_interval_s)
+                r = prp.run_prp_or_ll(eng, p, mode, max_iters=max_iters, checklevel=checklevel, log=log, on_check=on_check,
+                                      should_stop=should_stop, **kw)
             finally:
                 eng.close()
         except Exception as exc:   # a failing entry must not strand the other ranks in a collective
@@ -112,14 +132,26 @@ def run_sharded(worktodo_lines, make_engine, device="cpu", max_iters=None, check
                  "gerbicz_errors": 0, "complete": False, "state": None, "error": "%s: %s" % (type(exc).__name__, exc)}
         r["rank"] = rank
         with state_lock:
-            state["iters"] += r["iterations"] - base_iters[0]
-            if r.get("error") or (max_iters is None and not r["complete"]):
+            state["iters"] += max(r["iterations"] - base_iters[0], 0)
+            if r.get("error") or (max_iters is None and not r["complete"] and not r.get("interrupted")):
                 state["ok"] = 0
             results.append(r)
+        while owed > 0:       # the entry ended before its last boundary: the peers still expect these reductions
+            owed -= 1
+            reduce_now()
+
+    def skipped(mode, p):   # entries a rank does not start after an interrupt: they keep their place in the worktodo
+        results.append({"exponent": p, "mode": mode, "is_prime": False, "res64": "", "res2048": "", "iterations": 0, "gerbicz_checks": 0,
+                        "gerbicz_errors": 0, "complete": False, "state": None, "interrupted": True, "rank": rank})
+        for _ in range(check_boundaries([(mode, p)], checklevel)[0] if lockstep else 0):
+            reducer.reduce(state["ok"], state["errors"], state["iters"])
 
     if per_gpu <= 1:
         for mode, p in mine:
-            one(mode, p)
+            if should_stop is not None and should_stop():
+                skipped(mode, p)
+            else:
+                one(mode, p)
     else:
         queue = list(mine)
         qlock = threading.Lock()
@@ -130,7 +162,11 @@ def run_sharded(worktodo_lines, make_engine, device="cpu", max_iters=None, check
                     if not queue:
                         return
                     mode, p = queue.pop(0)
-                one(mode, p)
+                if should_stop is not None and should_stop():
+                    with state_lock:
+                        skipped(mode, p)
+                else:
+                    one(mode, p)
         threads = [threading.Thread(target=worker) for _ in range(min(per_gpu, max(len(mine), 1)))]
         for t in threads:
             t.start()
@@ -164,6 +200,9 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo")
     ap.add_argument("--fft", default=None, help="transform spec handed to every engine: a plan (m2=..,c=..) or crt[:odd][:words=N] for the "
                     "GF(M61^2) x GF(M31^2) family with a prime-factor axis (the reference's -fft)")
+    ap.add_argument("--ckpt-dir", default=None, help="directory of the per-exponent checkpoint files (resume on start, save every "
+                    "--backup-interval seconds and on SIGINT / SIGTERM); default: no checkpoints")
+    ap.add_argument("--backup-interval", type=float, default=300.0, help="seconds between checkpoints (the reference's -t)")
     ap.add_argument("--dry-run", action="store_true", help="print the shard of every rank and exit (no GPU, no process group)")
     args = ap.parse_args(argv)
 
@@ -195,9 +234,15 @@ def main(argv=None):
         if rank == 0:
             sys.stderr.write("[status] %s\n" % json.dumps(st))
 
+    # SIGINT / SIGTERM: every running entry checkpoints at its next iteration and returns (RunPrpOrLlMarin.cpp:296-309);
+    # the rank then goes through the same exit reductions as a finished one
+    stop = threading.Event()
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        signal.signal(sig, lambda *_: stop.set())
     try:
         results, status = run_sharded(lines, lambda p: Engine(p, prp.REGISTERS, device=local_rank, plan=args.fft), device=device, max_iters=args.max_iters,
-                                      checklevel=args.checklevel, log=log, per_gpu=args.per_gpu, on_status=on_status)
+                                      checklevel=args.checklevel, log=log, per_gpu=args.per_gpu, on_status=on_status, should_stop=stop.is_set,
+                                      ckpt_dir=args.ckpt_dir, backup_interval_s=args.backup_interval)
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -205,8 +250,8 @@ def main(argv=None):
         with open(args.results, "a") as f:
             for r in sorted(results, key=lambda r: r["exponent"]):
                 if r.get("complete"):
-                    f.write(prp.result_json(r, 0) + "\n")
-        print(json.dumps({"status": status, "results": [{k: r[k] for k in ("exponent", "mode", "is_prime", "res64", "iterations", "complete", "rank") if k in r} |
+                    f.write(prp.result_json(r, r.get("fft_length", 0)) + "\n")
+        print(json.dumps({"status": status, "results": [{k: r[k] for k in ("exponent", "mode", "is_prime", "res64", "iterations", "complete", "interrupted", "rank") if k in r} |
                                                          ({"error": r["error"]} if r.get("error") else {}) for r in results]}))
     return 0 if status["all_ok"] == 1 else 1
 

@@ -129,6 +129,41 @@ def load_checkpoint(path, eng, p, mode):
     return it, elapsed
 
 
+# Gerbicz-Li rollback point next to the checkpoint (the reference keeps itersave / jsave in its backup manager and reloads
+# them on a resume, RunPrpOrLlMarin.cpp:251-255): iteration of the checkpoint they belong to, itersave, jsave, checkpass, CRC.
+GL_MAGIC = 0x474C3352   # "GL3R"
+
+
+def gerbicz_state_name(ckpt_path):
+    return ckpt_path + ".gl"
+
+
+def save_gerbicz_state(ckpt_path, it, itersave, jsave, checkpass):
+    body = struct.pack("<IIQQQ", GL_MAGIC, it, itersave, jsave, checkpass)
+    tmp = gerbicz_state_name(ckpt_path) + ".new"
+    with open(tmp, "wb") as f:
+        f.write(body + struct.pack("<I", zlib.crc32(body) & 0xFFFFFFFF))
+    os.replace(tmp, gerbicz_state_name(ckpt_path))
+
+
+def load_gerbicz_state(ckpt_path, it):
+    """-> (itersave, jsave, checkpass) if the side file belongs to the checkpoint of iteration `it`, else None."""
+    try:
+        raw = open(gerbicz_state_name(ckpt_path), "rb").read()
+    except OSError:
+        return None
+    n = struct.calcsize("<IIQQQ")
+    if len(raw) != n + 4 or struct.unpack("<I", raw[n:])[0] != (zlib.crc32(raw[:n]) & 0xFFFFFFFF):
+        return None
+    magic, sit, itersave, jsave, checkpass = struct.unpack("<IIQQQ", raw[:n])
+    if magic != GL_MAGIC or sit != it:
+        return None
+    return int(itersave), int(jsave), int(checkpass)
+
+
+MAX_GERBICZ_ERRORS = 64   # a run that keeps failing its checks is stopped (hardware that is not fit for the job)
+
+
 # ---------------------------------------------------------------------------------------------
 # worktodo (WorktodoParser.cpp:78-400): only what the one-exponent-per-GPU sharder needs
 # ---------------------------------------------------------------------------------------------
@@ -167,7 +202,8 @@ def shard_worktodo(lines, rank, world):
 # the driver
 # ---------------------------------------------------------------------------------------------
 def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, max_iters=None,
-                  log=None, ckpt_path=None, backup_every=0, resume=None, stop_after_s=None, on_check=None):
+                  log=None, ckpt_path=None, backup_every=0, resume=None, stop_after_s=None, on_check=None, should_stop=None,
+                  backup_interval_s=None):
     """One PRP (mode "prp") or LL-unsafe (mode "ll") test of 2^p-1 on `eng` (>= 8 registers).
 
     Returns a dict: is_prime, res64, res2048, iterations, gerbicz_checks, gerbicz_errors, complete.
@@ -178,6 +214,11 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     passed check after that many seconds and return that state in result["state"] (long runs in slices).
     on_check(passed, iteration) is called after every Gerbicz-Li check (the multi-GPU launcher reduces its status
     word there).
+    backup_every (iterations) / backup_interval_s (seconds, the reference's -t, RunPrpOrLlMarin.cpp:311-319): checkpoint cadence.
+    should_stop(): polled before every iteration; when it returns true the state is checkpointed (ckpt_path) and the run
+    returns with complete = False and interrupted = True -- the reference's SIGINT path (RunPrpOrLlMarin.cpp:296-309).
+    A checkpoint carries the Gerbicz-Li rollback point (R4 / R5 inside the register dump, itersave / jsave / checkpass in
+    the side file): a check that fails after a resume rolls back to the block the checkpoint itself was verified from.
     """
     import time as _time
     t_start = _time.time()
@@ -185,16 +226,22 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     prp = mode == "prp"
     total = p if prp else p - 2
     ri = 0
+    gl = None
     if ckpt_path:
-        got = load_checkpoint(ckpt_path, eng, p, mode) or load_checkpoint(ckpt_path + ".old", eng, p, mode)
+        got = load_checkpoint(ckpt_path, eng, p, mode)
+        if got:
+            gl = load_gerbicz_state(ckpt_path, got[0])
+        else:
+            got = load_checkpoint(ckpt_path + ".old", eng, p, mode)
         if got:
             ri = got[0]
             log("Resuming from a checkpoint.")
     if ri == 0 and resume is None:
         eng.set(R1, 1)
         eng.set(R0, 3 if prp else 4)
-    eng.copy(R4, R0)          # last state that passed a check
-    eng.copy(R5, R1)
+    if gl is None:            # else R4 / R5 of the checkpoint are the state the rollback point names
+        eng.copy(R4, R0)      # last state that passed a check
+        eng.copy(R5, R1)
     eng.set(RBASE, 3)
     eng.set_multiplicand(RTMP, RBASE)
 
@@ -209,14 +256,34 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     checks = errors = 0
     done = 0
     it, j = ri, total - ri - 1
+    if gl is not None:
+        itersave, jsave, checkpass = gl
+    elif ri > 0:
+        # no rollback point on file: R4 / R5 hold the resumed state itself, so a rollback re-enters the loop at ri
+        itersave, jsave = ri - 1, total - ri
     if resume is not None:
         itersave, jsave = int(resume["it"]), int(resume["j"])
         it, j = itersave + 1, jsave - 1
     state = None
+    interrupted = False
+
+    last_backup = [t_start]
+
+    def checkpoint(at):
+        save_checkpoint(ckpt_path, eng, p, mode, at, _time.time() - t_start)
+        save_gerbicz_state(ckpt_path, at, itersave, jsave, checkpass)
+        last_backup[0] = _time.time()
+
     while it < total:
         if max_iters is not None and done >= max_iters:
             break
         if state is not None:
+            break
+        if should_stop is not None and should_stop():
+            interrupted = True
+            if ckpt_path:
+                checkpoint(it)
+            log("Interrupted, state saved at iteration %d j=%d" % (it, j))
             break
         eng.square_mul(R0)
         if not prp:
@@ -257,6 +324,8 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
                         it -= 1
                         j += 1
                     errors += 1
+                    if errors > MAX_GERBICZ_ERRORS:
+                        raise RuntimeError("Gerbicz-Li check failed %d times: giving up on exponent %d" % (errors, p))
                     eng.copy(R0, R4)
                     eng.copy(R1, R5)
                 else:
@@ -266,10 +335,11 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
                     itersave, jsave = it, j
                     if stop_after_s is not None and _time.time() - t_start > stop_after_s and it != total - 1:
                         state = {"it": it, "j": j}
-        if ckpt_path and backup_every and done % backup_every == 0:
-            save_checkpoint(ckpt_path, eng, p, mode, it + 1, 0.0)
         it += 1
         j -= 1
+        if ckpt_path and it < total and ((backup_every and done % backup_every == 0) or
+                                         (backup_interval_s is not None and (done & 255) == 0 and _time.time() - last_backup[0] >= backup_interval_s)):
+            checkpoint(it)
 
     d = eng.digits(R0)
     if prp:
@@ -281,7 +351,8 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
         words = prp3_div9(p, words)
     return {"exponent": p, "mode": mode, "is_prime": bool(is_prime) and it >= total, "res64": format_res64(words),
             "res2048": format_res2048(words), "iterations": it, "gerbicz_checks": checks,
-            "gerbicz_errors": errors, "complete": it >= total, "state": state}
+            "gerbicz_errors": errors, "complete": it >= total, "state": state, "interrupted": interrupted,
+            "fft_length": int(getattr(eng, "n", 0))}
 
 
 # register roles of the LL-safe driver (RunLlSafeMarin.cpp:20-28: V, U, their last good copies, the re-run copies)
@@ -463,7 +534,10 @@ def run_ll_safe2(eng, p, erroriter=0, checklevel=0, max_iters=None, log=None):
             "complete": complete}
 
 
-def result_json(r, fft_length, program_version="mi355-marin-hip 0.1", port=8, user="", computer="", aid="", timestamp=""):
+PROGRAM_VERSION = "mi355-marin-hip 0.3"   # MI355_ENGINE_VERSION of include/mi355_engine.h
+
+
+def result_json(r, fft_length, program_version=PROGRAM_VERSION, port=8, user="", computer="", aid="", timestamp=""):
     """Result line in the reference's PrimeNet-style JSON (src/io/JsonBuilder.cpp:322-472): same keys, same
     order for the PRP / LL work types ("status" P/C, "worktype" PRP-3 / LL, res64, res2048 + residue-type 1
     for PRP, errors.gerbicz, shift-count 0, fft-length, program)."""

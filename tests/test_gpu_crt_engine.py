@@ -154,6 +154,31 @@ def test_prp_with_gerbicz_li_checks_on_the_crt_engine():
         assert not r["is_prime"] and r["gerbicz_errors"] == 1
 
 
+@pytest.mark.parametrize("odd", [3, 9])
+def test_reference_held_residues_on_the_crt_engine(odd):
+    """the vectors the reference's own test script holds (unit_tests.sh:166-178: Res64 of 3^(2^k) mod M11213 at k = 1000 ... 11000;
+    :152-153 its final type-1 residue; :140-141 res64 + res2048 of M100003) through the HIP engine of this family at radix 3 and 9 --
+    canonical residues do not depend on the field the transform runs in"""
+    import json
+    import os
+    from prmers_amd import prp
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+    want = {int(k): v for k, v in gold["m11213_intermediate_res64"].items() if k.isdigit()}
+    with CrtEngine(11213, odd) as e:
+        e.set(0, 3)
+        for k in range(1, 11213 + 1):
+            e.square_mul(0)
+            if k in want:
+                assert "%016X" % e.res64(0) == want[k], (odd, k)
+        assert e.get_int(0) == 9
+    with CrtEngine(100003, odd, reg_count=prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, 100003, "prp")
+        assert not r["is_prime"] and r["res64"] == gold["m100003"]["res64"] and r["res2048"] == gold["m100003"]["res2048"].lower()
+    with CrtEngine(11213, odd, reg_count=prp.REGISTERS) as e:
+        r = prp.run_prp_or_ll(e, 11213, "prp")
+        assert r["is_prime"] and r["res64"] == gold["m11213_final"]["res64"] and r["res2048"] == "0" * 511 + "1"
+
+
 def test_checkpoints_and_raw_images_on_the_crt_engine(tmp_path):
     """get_data / set_data / checkpoints (engine.h:134-146) with residues and a multiplicand image in the register file, and the caller's
     checkpoint file (prmers_amd/prp.py, version-2 layout) carrying a PRP across two engines"""

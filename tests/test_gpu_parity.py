@@ -407,39 +407,6 @@ def test_register_resident_columns_other_shapes_full_size(p, n, m1):
         assert e.res64(0) == o.res64(0)
 
 
-@pytest.mark.parametrize("fused", ["1", "2"])
-@pytest.mark.parametrize("p,plan", [(300007, "m2=8,c=4"), (300007, "m2=16,c=8"), (600011, "m2=8,c=2"), (136279841, None), (57885161, None)])
-def test_fused_back_front_sweep(p, plan, fused, monkeypatch):
-    """MI355_FUSED=1 (one fused kernel per tile) and =2 (back and front blocks chained in one launch): the
-    residue stays a front image between squarings (inter-work-group hand-off through flags); every engine
-    operation must still agree with the oracle."""
-    import prmers_amd
-    if not prmers_amd.LIB_PATH.endswith("_exp.so"):
-        pytest.skip("experimental kernels live in their own library: make -C prmers_amd/csrc exp; "
-                    "MI355_ENGINE_LIB=prmers_amd/libmi355_engine_exp.so python -m pytest tests -m gpu -k fused")
-    monkeypatch.setenv("MI355_FUSED", fused)
-    o = orc.Oracle(p, 4)
-    rng = np.random.default_rng(p)
-    w = o.widths().astype(np.uint64)
-    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
-    with Engine(p, 5, plan=plan) as e:
-        e.set_digits(0, d0); o.set_digits(0, d0)
-        for a in (1, 1, 3):
-            e.square_mul(0, a); o.square_mul(0, a)
-        assert np.array_equal(e.digits(0), o.digits(0))           # front image -> digits
-        for _ in range(3):                                         # LL steps: the subtraction rides on the front image
-            e.square_mul(0); e.sub(0, 2); o.square_mul(0); o.sub(0, 2)
-        e.copy(1, 0); o.copy(1, 0)                                 # copy of a front image with a pending subtraction
-        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)         # multiplicand straight from the front image
-        e.square_mul(0); o.square_mul(0)
-        e.mul(0, 2, 5); o.mul(0, 2, 5)
-        e.add(0, 1); o.add(0, 1)
-        e.square_mul(0); o.square_mul(0)
-        assert np.array_equal(e.digits(0), o.digits(0))
-        assert np.array_equal(e.digits(1), o.digits(1))
-        e.sync()
-
-
 @pytest.mark.parametrize("p", [9815459, 136279841, 205271257])
 def test_gmp_pins_at_baseline_exponents(p):
     """C2 / C3 / C4 from x0 = 3: res64, low 2048 bits and the SHA-256 of the canonical words at iterations

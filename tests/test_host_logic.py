@@ -125,6 +125,56 @@ def _build_cli(td):
     return exe
 
 
+def _build_oracle_shim(td):
+    """tests/host/oracle_abi_shim.c + oracle/oracle.c -> a library with the engine's C ABI served by the CPU oracle (tests only)"""
+    so = os.path.join(td, "liboracle_abi_shim.so")
+    subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-fvisibility=hidden", "-o", so,
+                           os.path.join(ROOT, "tests", "host", "oracle_abi_shim.c"), os.path.join(ROOT, "oracle", "oracle.c"), "-lm"])
+    return so
+
+
+def test_cpp_driver_resume_rollback_and_sigint_on_the_oracle(tmp_path):
+    """examples/prp_cli.cpp on CPU (engine_hip loading the oracle-backed ABI shim): (1) a partial run, a resume and an
+    injected error right after it roll back to the rollback point saved WITH the checkpoint (RunPrpOrLlMarin.cpp:251-255) and
+    end on the right residue; (2) SIGINT ends a running test with exit code 0 and a checkpoint (:296-309), and the resumed
+    run prints the reference's golden M100003 result line (unit_tests.sh:140-141)."""
+    import json
+    import signal
+    import time
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")))
+    exe, shim = _build_cli(str(tmp_path)), _build_oracle_shim(str(tmp_path))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    run = lambda *a: subprocess.run([exe, *a, "-lib", shim], capture_output=True, text=True, cwd=str(tmp_path), env=env)   # noqa: E731
+    # (1) p = 9941, checks at every block boundary; checkpoint at 5050 (inside a block), fault at 5060
+    o1 = run("9941", "-checklevel", "1", "-ckpt", str(tmp_path), "-maxiters", "5050")
+    assert o1.returncode == 0 and "partial run" in o1.stdout and (tmp_path / "m_9941.ckpt.gl").exists(), o1.stdout + o1.stderr
+    o2 = run("9941", "-checklevel", "1", "-ckpt", str(tmp_path), "-erroriter", "5060")
+    assert o2.returncode == 0, o2.stdout + o2.stderr
+    assert "Resuming from a checkpoint at iteration 5050" in o2.stdout and "Injected error at iteration 5060" in o2.stdout
+    restores = [l for l in o2.stdout.splitlines() if l.startswith("[Gerbicz Li] Restore")]
+    assert len(restores) == 1 and restores[0] == "[Gerbicz Li] Restore iter=4990 (j=4950)"   # last boundary before 5050: j = 9940 - iter = 50 * 99
+    assert "probably prime" in o2.stdout and "gerbicz_errors=1" in o2.stdout
+    # the same without the side file: the rollback lands on the resumed state itself
+    o1 = run("9941", "-checklevel", "1", "-ckpt", str(tmp_path), "-maxiters", "5050")
+    os.remove(tmp_path / "m_9941.ckpt.gl")
+    o3 = run("9941", "-checklevel", "1", "-ckpt", str(tmp_path), "-erroriter", "5060")
+    assert "[Gerbicz Li] Restore iter=5049 (j=4891)" in o3.stdout and "probably prime" in o3.stdout and "gerbicz_errors=1" in o3.stdout, o3.stdout
+    # (2) SIGINT while M100003 runs, then the resume
+    proc = subprocess.Popen([exe, "100003", "-ckpt", str(tmp_path), "-json", "results.json.txt", "-lib", shim], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True, cwd=str(tmp_path), env=env)
+    time.sleep(3.0)
+    proc.send_signal(signal.SIGINT)
+    out, err = proc.communicate(timeout=120)
+    assert proc.returncode == 0 and "Interrupted by user, state saved at iteration" in out, out + err
+    assert (tmp_path / "m_100003.ckpt").exists() and not (tmp_path / "results.json.txt").exists()
+    o4 = run("100003", "-ckpt", str(tmp_path), "-json", "results.json.txt")
+    assert o4.returncode == 0 and "Resuming from a checkpoint" in o4.stdout, o4.stdout + o4.stderr
+    line = json.loads((tmp_path / "results.json.txt").read_text().splitlines()[-1])
+    m = gold["m100003"]
+    assert line["res64"] == m["res64"] == "1CF45E9503C71FD6" and line["res2048"] == m["res2048"].lower() and line["status"] == "C"
+    assert line["errors"] == {"gerbicz": 0}
+
+
 def test_cpp_driver_fails_loudly_without_gpu():
     from prmers_amd import engine as E
     import torch

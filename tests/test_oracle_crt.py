@@ -64,3 +64,43 @@ def test_big_p_pins_at_the_pfa_sizes_of_config_4(n):
             w = o.words()
             assert "%016X" % (int(w[0]) | (int(w[1]) << 32)) == pins[it]["res64"]
             assert hashlib.sha256(w.astype("<u4").tobytes()).hexdigest() == pins[it]["sha256_words"]
+
+
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")))
+
+
+def _res64(words):
+    return "%016X" % (int(words[0]) | (int(words[1]) << 32))
+
+
+@pytest.mark.parametrize("odd", [1, 3, 9])
+def test_reference_held_m11213_residues_pin_this_oracle(odd):
+    """unit_tests.sh:166-178 (Res64 of 3^(2^k) mod M11213 at k = 1000 ... 11000) and :152-153 (type-1 residue of the finished test):
+    canonical residues do not depend on the field, so the vectors the reference holds for its Marin path pin this family as they stand"""
+    import prmers_amd.prp as prp
+    p = 11213
+    want = {int(k): v for k, v in GOLD["m11213_intermediate_res64"].items() if k.isdigit()}
+    assert sorted(want) == list(range(1000, 11001, 1000))
+    o = orc_crt.OracleCrt(p, odd)
+    o.set(3)
+    for k in range(1, p + 1):
+        o.square_mul()
+        if k in want:
+            assert _res64(o.words()) == want[k], (odd, k)
+    assert o.value() == 9                                    # 3^(2^p) = 9: M11213 is prime
+    w = prp.prp3_div9(p, o.words())
+    assert prp.format_res64(w) == GOLD["m11213_final"]["res64"] and prp.format_res2048(w) == "0" * 511 + "1"
+
+
+@pytest.mark.parametrize("odd", [3, 9])
+def test_reference_held_m100003_residue_pins_this_oracle(odd):
+    """unit_tests.sh:140-141: res64 and res2048 of the type-1 PRP residue of the composite M100003"""
+    import prmers_amd.prp as prp
+    p = 100003
+    o = orc_crt.OracleCrt(p, odd)
+    o.set(3)
+    for _ in range(p):
+        o.square_mul()
+    w = prp.prp3_div9(p, o.words())
+    assert prp.format_res64(w) == GOLD["m100003"]["res64"]
+    assert prp.format_res2048(w) == GOLD["m100003"]["res2048"].lower()

@@ -92,6 +92,66 @@ def test_checkpoint_roundtrip_and_resume(kind, tmp_path):
         assert prp.load_checkpoint(path + ".old", e, p, "prp") is not None
 
 
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("side_file", [True, False])
+def test_failed_check_after_a_resume_rolls_back_to_the_saved_point(kind, side_file, tmp_path):
+    """A checkpoint written in the middle of a Gerbicz-Li block, a resume, then a fault: the rollback must land on the
+    (iteration, R4 / R5) pair the checkpoint was saved with (RunPrpOrLlMarin.cpp:251-255 reloads itersave / jsave) --
+    or, without the side file, on the resumed state itself -- and the run must still end on the known residue."""
+    p = 9941
+    path = prp.checkpoint_name(p, "prp", str(tmp_path))
+    with make_engine(kind, p) as e:
+        part = prp.run_prp_or_ll(e, p, "prp", checklevel=1, max_iters=5050, ckpt_path=path, backup_every=1010)
+    assert not part["complete"] and part["gerbicz_errors"] == 0
+    assert prp.load_gerbicz_state(path, 5050) is not None
+    itersave = prp.load_gerbicz_state(path, 5050)[0]
+    assert 0 < itersave < 5050
+    if not side_file:
+        os.remove(prp.gerbicz_state_name(path))
+    msgs = []
+    with make_engine(kind, p) as e:
+        r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, ckpt_path=path, erroriter=5060, log=msgs.append)
+    assert "Resuming from a checkpoint." in msgs and "Injected error at iteration 5060" in msgs
+    restored = [m for m in msgs if m.startswith("[Gerbicz Li] Restore")]
+    assert len(restored) == 1
+    assert restored[0].startswith("[Gerbicz Li] Restore iter=%d " % (itersave if side_file else 5049))
+    assert r["gerbicz_errors"] == 1 and r["complete"] and r["is_prime"] and r["res64"] == "0000000000000001"
+    # no squaring is done twice beyond the rolled-back block
+    assert r["iterations"] == p
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_interrupt_checkpoints_and_the_resume_reaches_the_golden_residue(kind, tmp_path):
+    """SIGINT path of the reference (RunPrpOrLlMarin.cpp:296-309): state saved at the iteration the flag is seen, clean
+    return; the resumed run ends on the reference's M11213 residue."""
+    p = 11213
+    path = prp.checkpoint_name(p, "prp", str(tmp_path))
+    polls = [0]
+
+    def stop():
+        polls[0] += 1
+        return polls[0] > 4321
+    msgs = []
+    with make_engine(kind, p) as e:
+        part = prp.run_prp_or_ll(e, p, "prp", ckpt_path=path, should_stop=stop, log=msgs.append)
+    assert part["interrupted"] and not part["complete"] and part["iterations"] == 4321
+    assert "Interrupted, state saved at iteration 4321 j=%d" % (p - 4321 - 1) in msgs
+    with make_engine(kind, p) as e:
+        r = prp.run_prp_or_ll(e, p, "prp", ckpt_path=path)
+    assert r["complete"] and r["is_prime"] and r["res64"] == GOLD["m11213_final"]["res64"] and r["gerbicz_errors"] == 0
+
+
+def test_a_run_that_keeps_failing_its_checks_gives_up():
+    p = 127
+
+    class Liar(orc.OracleEngine):
+        def is_equal(self, a, b):
+            return False
+    with Liar(p, prp.REGISTERS) as e:
+        with pytest.raises(RuntimeError, match="giving up"):
+            prp.run_prp_or_ll(e, p, "prp", checklevel=1)
+
+
 def test_worktodo_parsing_and_sharding():
     lines = ["# comment", "PRP=1,2,136279841,-1", "PRP=0123456789ABCDEF0123456789ABCDEF,1,2,136279879,-1,76,0",
              "Test=136279901", "DoubleCheck=0123456789abcdef0123456789abcdef,85473391,76,1", "Test=1,2,127,-1",

@@ -37,6 +37,34 @@ def _worker(rank, world, port, q, scenario):
         elif scenario == "check_fails":   # an injected error on one entry: caught by Gerbicz-Li, rolled back, and reported
             res, status = launch.run_sharded(["PRP=1,2,9941,-1", "PRP=1,2,127,-1"], lambda p: orc.OracleEngine(p, prp.REGISTERS),
                                              checklevel=1, erroriter=(9900 if rank == 0 else 0))
+        elif scenario == "lockstep_error":   # a failed check on ONE rank under boundary reductions (rollback repeats its boundaries)
+            res, status = launch.run_sharded(["PRP=1,2,521,-1", "PRP=1,2,523,-1"], lambda p: orc.OracleEngine(p, prp.REGISTERS), checklevel=1,
+                                             on_status=seen.append, erroriter=(500 if rank == 0 else 0))
+        elif scenario == "lockstep_raise":   # an engine that dies in the middle of rank 1's entry: rank 0 keeps reducing at its boundaries
+            class Dying(orc.OracleEngine):
+                count = 0
+
+                def square_mul(self, r, a=1):
+                    Dying.count += 1
+                    if Dying.count > 300:
+                        raise RuntimeError("HIP error: device lost")
+                    return orc.OracleEngine.square_mul(self, r, a)
+            res, status = launch.run_sharded(["PRP=1,2,521,-1", "PRP=1,2,523,-1"],
+                                             lambda p: (Dying if p == 523 else orc.OracleEngine)(p, prp.REGISTERS), checklevel=1, on_status=seen.append)
+        elif scenario == "interrupt":   # a stop request on both ranks: checkpoint, clean return; a second launch resumes and finishes
+            import tempfile
+            d = os.path.join(tempfile.gettempdir(), "mi355_gloo_ckpt_%d" % port)
+            os.makedirs(d, exist_ok=True)
+            polls = [0]
+
+            def stop():
+                polls[0] += 1
+                return polls[0] > 200
+            res1, st1 = launch.run_sharded(WORKTODO, lambda p: orc.OracleEngine(p, prp.REGISTERS), checklevel=1, should_stop=stop, ckpt_dir=d)
+            assert st1["all_ok"] == 1 and all((not r["complete"]) for r in res1 if r["exponent"] != 127), (st1, res1)
+            assert any(r.get("interrupted") for r in res1)
+            res, status = launch.run_sharded(WORKTODO, lambda p: orc.OracleEngine(p, prp.REGISTERS), checklevel=1, ckpt_dir=d)
+            status["first_run_iterations"] = st1["iterations"]
         q.put((rank, [(r["exponent"], r["mode"], r["is_prime"], r["rank"], r.get("error")) for r in res], status, len(seen)))
     finally:
         dist.destroy_process_group()
@@ -86,6 +114,31 @@ def test_a_failed_gerbicz_check_is_counted_and_clears_all_ok():
     for rank, res, status, _ in _run("check_fails"):
         assert status["gerbicz_errors"] == 1 and status["all_ok"] == 0
         assert (9941, "prp", True, 0, None) in res              # the run recovered from the last good state
+
+
+def test_a_failed_check_on_one_rank_keeps_the_boundary_reductions_matched():
+    for rank, res, status, nseen in _run("lockstep_error"):
+        assert status["check_boundary_reductions"] is True and status["gerbicz_errors"] == 1 and status["all_ok"] == 0
+        assert nseen == 24 + 1                               # same count as without the fault: re-visited boundaries do not reduce
+        assert sorted((r[0], r[2]) for r in res) == [(521, True), (523, False)]
+
+
+def test_an_entry_that_dies_mid_run_still_issues_the_reductions_it_owes():
+    for rank, res, status, nseen in _run("lockstep_raise"):
+        assert status["check_boundary_reductions"] is True and status["all_ok"] == 0 and nseen == 24 + 1
+        errs = [r for r in res if r[4]]
+        assert len(errs) == 1 and errs[0][0] == 523 and "device lost" in errs[0][4]
+        assert (521, "prp", True, 0, None) in res
+
+
+def test_interrupt_checkpoints_every_rank_and_a_second_launch_resumes():
+    expected = sorted([(127, "prp", True, 0, None), (607, "ll", True, 0, None), (521, "prp", True, 1, None), (1001, "prp", False, 1, None)])
+    for rank, res, status, _ in _run("interrupt"):
+        assert sorted(res) == expected and status["all_ok"] == 1
+        # the 201st poll of a rank stops it (one poll per entry + one per iteration): rank 0 finished 127 and got 71 iterations into
+        # 607, rank 1 got 199 into 521 and never started 1001; the second launch resumes both from their checkpoints
+        assert status["first_run_iterations"] == 127 + 71 + 199
+        assert status["iterations"] == 605 + 521 + 1001 + 127     # (127 has no checkpoint after its last iteration: it runs again)
 
 
 def test_launcher_command_line_dry_run(tmp_path):
