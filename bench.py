@@ -12,6 +12,9 @@ region.  Rank 0 prints ONE JSON line.  Extra objects:
                   duration from HIP events on the engine's stream (one event between kernels, minus the
                   measured cost of an event record: agrees with rocprofv3 --kernel-trace), against the
                   8 TB/s HBM peak
+  roofline.valu -- the binding roof as a number: VALU instructions and issue cycles per wave of each kernel from the ISA walk
+                  (tools/valu_model.py -> profiles/valu_model_latest.json), predicted_us = waves per SIMD x cycles / 2.4 GHz,
+                  frac = predicted / measured per kernel and for the squaring
   preheat      -- untimed squarings before --warmup until the GPU clock has ramped (a cold box runs the
                   first tens of milliseconds slower; --steps/--warmup keep their meaning)
   cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference has no CPU
@@ -193,9 +196,13 @@ def main():
 
     status = torch.tensor([1, 0, args.steps], dtype=torch.int64, device=red_dev)   # ok, gerbicz errors, iterations
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    per_rank = [{"rank": rank, "device": local_rank, "exponent": p, "ms_per_step": round(1e3 * elapsed / args.steps, 5)}]
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(status, op=dist.ReduceOp.SUM)   # the only cross-GPU traffic: a 24-byte status word
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])    # what every rank ran and how long it took (reported, not timed)
+        per_rank = gathered
     elapsed = float(tmax.item())
 
     # BASELINE configs[2] is the LL form of the same exponent (x^2 - 2): a short untimed-region measurement
@@ -229,6 +236,27 @@ def main():
                 traffic = tj.get(dom)
         except Exception:
             traffic = None
+        valu = None
+        try:   # the VALU issue model of the three kernels (ISA walk, tools/valu_model.py) against this run's kernel times
+            vm = json.load(open(os.path.join(ROOT, "profiles", "valu_model_latest.json")))
+            if vm.get("plan") == __import__("prmers_amd").resolve_plan(p, args.plan):
+                ks = {}
+                for k, v in vm["kernels"].items():
+                    if k in chain:
+                        ks[k] = {"insts": int(round(v["valu_insts_per_wave"] * vm["waves_per_launch"])), "issue_cycles_per_wave": v["issue_cycles_per_wave"],
+                                 "predicted_us": v["predicted_us"], "measured_us": round(chain[k] * 1e3, 2),
+                                 "frac": round(v["predicted_us"] / (chain[k] * 1e3), 4)}
+                pred = sum(v["predicted_us"] for v in ks.values())
+                valu = {"insts": sum(v["insts"] for v in ks.values()), "issue_cycles": round(sum(v["issue_cycles_per_wave"] for v in ks.values()), 1),
+                        "predicted_us": round(pred, 2), "measured_us": round(ms_per_step * 1e3, 2), "frac": round(pred / (ms_per_step * 1e3), 4),
+                        "clock_ghz_assumed": vm["clock_ghz"], "kernels": ks,
+                        "steady_state_frac": {"k_front": 0.95, "k_middle": 1.0, "k_back": 0.99},
+                        "note": "frac = predicted VALU issue time / measured time.  steady_state_frac: the same against the marginal cost of 1024 more tiles in "
+                                "one launch (profiles/r03_probe_timeline.md): the kernels sit on the VALU roof, the rest is a fixed cost per launch "
+                                "(launch-to-launch gap, unequal XCD clocks, entry loads and single-group tails)",
+                        "source": "profiles/valu_model_latest.json (tools/valu_model.py)"}
+        except Exception:
+            valu = None
         out = {
             "metric": "PRP squaring throughput at p~136M (Marin IBDWT, one exponent per GPU)",
             "value": round(world * args.steps / elapsed, 3),
@@ -245,6 +273,7 @@ def main():
             "config": {"workload": "square_mul x<-x^2 mod 2^p-1, p=%d, n=%d words" % (p, n),
                        "plan": __import__("prmers_amd").resolve_plan(p, args.plan),
                        "exponents": EXPONENTS[:world] if not args.exponent else [p],
+                       "per_rank": per_rank,
                        "status_reduction_backend": args.dist_backend if world > 1 else None,
                        "parallelism": "replicas: one exponent per GPU, no data-path collective" +
                                       (" [REHEARSAL: all ranks on one device]" if rehearsal else "")},
@@ -256,6 +285,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
                          "binding_roof": "VALU issue (integer GF(P) arithmetic), see DESIGN.md section 5",
+                         "valu": valu,
                          "algorithmic_bytes_per_launch": sweep_bytes,
                          "kernel_ms": {k: round(v, 5) for k, v in kern.items()},
                          "kernel_ms_sum": round(sum(chain.values()), 5), "event_record_ms_subtracted": round(event_overhead, 5),

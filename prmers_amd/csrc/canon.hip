@@ -21,42 +21,47 @@
 namespace mi355 {
 namespace {
 
-struct CanonGeom { uint32_t p, n, logn2, r5, M1, M2, C; };   // n = r5 * 2^logn2
+struct CanonGeom { uint32_t p, n, logn2, r5, M1, M2, C; };   // n = r5 * 2^logn2 (r5: the odd factor 1, 3, 5 or 9); M1 = 0: natural digit order
 
 __device__ __forceinline__ uint64_t ceil_pj_n(const CanonGeom& g, uint64_t j) {
   const uint64_t x = uint64_t(g.p) * j + (g.n - 1);
   const uint64_t y = x >> g.logn2;
-  return g.r5 == 5 ? y / 5 : y;
+  return g.r5 == 1 ? y : y / g.r5;
 }
 __device__ __forceinline__ uint32_t width_of(const CanonGeom& g, uint64_t j) { return uint32_t(ceil_pj_n(g, j + 1) - ceil_pj_n(g, j)); }
 
 // memory position of natural digit j (plan.hpp Plan::pos)
 __device__ __forceinline__ size_t pos_of(const CanonGeom& g, uint32_t j) {
+  if (g.M1 == 0) return j;
   const uint32_t i = j >> 1, b = j & 1;
   const uint32_t i1 = i / g.M2, i2 = i - i1 * g.M2;
   const uint32_t T = i2 / g.C, c = i2 - T * g.C;
   return ((size_t(T) * g.M1 + i1) * g.C + c) * 2 + b;
 }
 
-__global__ void __launch_bounds__(256) k_gather(CanonGeom g, const uint32_t* __restrict__ digits, uint32_t* __restrict__ nat) {
+// T: digit type, uint32_t (Goldilocks engine, widths < 32) or uint64_t (the GF(M61^2) x GF(M31^2) engine: widths up to 39 bits)
+template <class T>
+__global__ void __launch_bounds__(256) k_gather(CanonGeom g, const T* __restrict__ digits, T* __restrict__ nat) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j < g.n) nat[j] = digits[pos_of(g, j)];
 }
 
-__global__ void __launch_bounds__(256) k_local(CanonGeom g, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+template <class T>
+__global__ void __launch_bounds__(256) k_local(CanonGeom g, const T* __restrict__ in, T* __restrict__ out) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= g.n) return;
   const uint32_t jp = j ? j - 1 : g.n - 1;
   const uint64_t o0 = ceil_pj_n(g, jp), o1 = ceil_pj_n(g, uint64_t(jp) + 1), o2 = ceil_pj_n(g, uint64_t(j) + 1);
   const uint32_t wp = uint32_t(o1 - o0);
   const uint32_t w = uint32_t(o2 - (j ? o1 : 0));   // for j = 0 the previous digit is n - 1: o1 = p, offset of digit 0 is 0
-  out[j] = (in[j] & ((1u << w) - 1u)) + (in[jp] >> wp);
+  out[j] = (in[j] & ((T(1) << w) - T(1))) + (in[jp] >> wp);
 }
 
 constexpr int kPerThread = 16, kBlockDigits = 256 * kPerThread;
 
 // (G, P) of the thread's digits / of the block.  Digit value v <= 2^w: generates iff v == 2^w, propagates iff v == 2^w - 1.
-__global__ void __launch_bounds__(256) k_scan_blocks(CanonGeom g, const uint32_t* __restrict__ nat, uint32_t* __restrict__ agg, uint32_t* __restrict__ err) {
+template <class T>
+__global__ void __launch_bounds__(256) k_scan_blocks(CanonGeom g, const T* __restrict__ nat, uint32_t* __restrict__ agg, uint32_t* __restrict__ err) {
   __shared__ uint32_t sg[256], sp[256];
   const uint32_t t = threadIdx.x, j0 = blockIdx.x * kBlockDigits + t * kPerThread;
   uint32_t G = 0, Pm = 1;
@@ -66,9 +71,9 @@ __global__ void __launch_bounds__(256) k_scan_blocks(CanonGeom g, const uint32_t
     if (j >= g.n) break;
     const uint64_t on = ceil_pj_n(g, uint64_t(j) + 1);
     const uint32_t w = uint32_t(on - o); o = on;
-    const uint32_t v = nat[j];
-    if (v > (1u << w)) atomicOr(err, 1u);   // cannot happen after the local passes (the caller falls back to the host carry)
-    const uint32_t gj = v >> w, pj = (v == (1u << w) - 1u) ? 1u : 0u;
+    const T v = nat[j];
+    if (v > (T(1) << w)) atomicOr(err, 1u);   // cannot happen after the local passes (the caller falls back to the host carry)
+    const uint32_t gj = uint32_t(v >> w), pj = (v == (T(1) << w) - T(1)) ? 1u : 0u;
     G = gj | (pj & G);
     Pm &= pj;
   }
@@ -106,11 +111,13 @@ __global__ void __launch_bounds__(256) k_scan_top(const uint32_t* __restrict__ a
   for (uint32_t b = b0; b < b1; ++b) { cin[b] = c; const uint32_t a = agg[b]; c = (a & 1u) | ((a >> 1) & c); }
 }
 
-__global__ void __launch_bounds__(256) k_apply(CanonGeom g, const uint32_t* __restrict__ nat, const uint32_t* __restrict__ cin, const uint32_t* __restrict__ flags,
-                                               uint32_t* __restrict__ out) {
+template <class T>
+__global__ void __launch_bounds__(256) k_apply(CanonGeom g, const T* __restrict__ nat, const uint32_t* __restrict__ cin, const uint32_t* __restrict__ flags,
+                                               T* __restrict__ out) {
   __shared__ uint32_t sg[256], sp[256], sc[256];
   const uint32_t t = threadIdx.x, j0 = blockIdx.x * kBlockDigits + t * kPerThread;
-  uint32_t v[kPerThread], w[kPerThread];
+  T v[kPerThread];
+  uint32_t w[kPerThread];
   uint32_t G = 0, Pm = 1;
   uint64_t o = (j0 < g.n) ? ceil_pj_n(g, j0) : 0;
 #pragma unroll
@@ -121,7 +128,7 @@ __global__ void __launch_bounds__(256) k_apply(CanonGeom g, const uint32_t* __re
       const uint64_t on = ceil_pj_n(g, uint64_t(j) + 1);
       w[k] = uint32_t(on - o); o = on;
       v[k] = nat[j];
-      const uint32_t gj = v[k] >> w[k], pj = (v[k] == (1u << w[k]) - 1u) ? 1u : 0u;
+      const uint32_t gj = uint32_t(v[k] >> w[k]), pj = (v[k] == (T(1) << w[k]) - T(1)) ? 1u : 0u;
       G = gj | (pj & G);
       Pm &= pj;
     }
@@ -139,9 +146,9 @@ __global__ void __launch_bounds__(256) k_apply(CanonGeom g, const uint32_t* __re
   for (int k = 0; k < kPerThread; ++k) {
     const uint32_t j = j0 + k;
     if (j < g.n) {
-      const uint32_t s = v[k] + c;
-      out[j] = zero ? 0u : (s & ((1u << w[k]) - 1u));
-      c = s >> w[k];
+      const T s = v[k] + c;
+      out[j] = zero ? T(0) : (s & ((T(1) << w[k]) - T(1)));
+      c = uint32_t(s >> w[k]);
     }
   }
 }
@@ -175,10 +182,35 @@ __global__ void k_set_small(CanonGeom g, uint32_t* __restrict__ digits, uint32_t
   }
 }
 
-__global__ void __launch_bounds__(256) k_compare(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t n, uint32_t* __restrict__ diff) {
+template <class T>
+__global__ void __launch_bounds__(256) k_compare(const T* __restrict__ a, const T* __restrict__ b, uint32_t n, uint32_t* __restrict__ diff) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   const bool ne = (j < n) && (a[j] != b[j]);
   if (__any(ne) && (threadIdx.x & 63) == 0) atomicOr(diff, 1u);
+}
+
+// dst[j] += (2^w_j - 1) - canon[j]: the digit-wise complement of a canonical residue, i.e. dst - src mod 2^p - 1 (engine::sub_reg)
+template <class T>
+__global__ void __launch_bounds__(256) k_add_complement(CanonGeom g, T* __restrict__ dst, const T* __restrict__ canon) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= g.n) return;
+  const uint32_t w = width_of(g, j);
+  dst[pos_of(g, j)] += ((T(1) << w) - T(1)) - canon[j];
+}
+
+// the whole pipeline on an array in natural order or tile-major order (g.M1)
+template <class T>
+void launch_pipeline(const CanonGeom& g, const T* digits, T* out, T* A, T* B, uint32_t* agg, uint32_t* cin, uint32_t* flags, hipStream_t s) {
+  const uint32_t n = g.n, nb = (n + kBlockDigits - 1) / kBlockDigits, ge = (n + 255) / 256;
+  const T* first = digits;
+  if (g.M1 != 0) { hipLaunchKernelGGL(k_gather<T>, dim3(ge), dim3(256), 0, s, g, digits, A); first = A; }
+  CanonGeom gn = g; gn.M1 = 0;   // from here on everything is in natural order
+  hipLaunchKernelGGL(k_local<T>, dim3(ge), dim3(256), 0, s, gn, first, B);
+  hipLaunchKernelGGL(k_local<T>, dim3(ge), dim3(256), 0, s, gn, B, A);
+  hipLaunchKernelGGL(k_local<T>, dim3(ge), dim3(256), 0, s, gn, A, B);
+  hipLaunchKernelGGL(k_scan_blocks<T>, dim3(nb), dim3(256), 0, s, gn, B, agg, flags + 1);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, agg, nb, cin, flags);
+  hipLaunchKernelGGL(k_apply<T>, dim3(nb), dim3(256), 0, s, gn, B, cin, flags, out);
 }
 
 CanonGeom geom_of(const DevPlan& pl, uint32_t p) {
@@ -201,19 +233,9 @@ size_t canon_scratch_words(const DevPlan& pl) {
 // too wide for the 0/1 carry chain (sticky; the caller then uses the host carry), [2] compare result (sticky).
 hipError_t canon_launch(const DevPlan& pl, uint32_t p, const uint32_t* digits, uint32_t* out, uint32_t* scratch, hipStream_t s) {
   const CanonGeom g = geom_of(pl, p);
-  const uint32_t n = pl.n, nb = (n + kBlockDigits - 1) / kBlockDigits, ge = (n + 255) / 256;
-  uint32_t* A = scratch;
-  uint32_t* B = scratch + n;
+  const uint32_t n = pl.n, nb = (n + kBlockDigits - 1) / kBlockDigits;
   uint32_t* agg = scratch + 2 * size_t(n);
-  uint32_t* cin = agg + nb;
-  uint32_t* flags = cin + nb;
-  hipLaunchKernelGGL(k_gather, dim3(ge), dim3(256), 0, s, g, digits, A);
-  hipLaunchKernelGGL(k_local, dim3(ge), dim3(256), 0, s, g, A, B);
-  hipLaunchKernelGGL(k_local, dim3(ge), dim3(256), 0, s, g, B, A);
-  hipLaunchKernelGGL(k_local, dim3(ge), dim3(256), 0, s, g, A, B);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, s, g, B, agg, flags + 1);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, agg, nb, cin, flags);
-  hipLaunchKernelGGL(k_apply, dim3(nb), dim3(256), 0, s, g, B, cin, flags, out);
+  launch_pipeline<uint32_t>(g, digits, out, scratch, scratch + n, agg, agg + nb, agg + 2 * nb, s);
   return hipGetLastError();
 }
 uint32_t* canon_flags(const DevPlan& pl, uint32_t* scratch) {
@@ -233,7 +255,46 @@ hipError_t canon_set_small(const DevPlan& pl, uint32_t p, uint32_t* digits, uint
   return hipGetLastError();
 }
 hipError_t canon_compare(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* diff_flag, hipStream_t s) {
-  hipLaunchKernelGGL(k_compare, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, diff_flag);
+  hipLaunchKernelGGL(k_compare<uint32_t>, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, diff_flag);
+  return hipGetLastError();
+}
+
+// ---- the same for the second field family: u64 digits in natural order, n = odd * 2^ln (crt_engine.hip) ----
+static CanonGeom geom64(uint32_t p, uint32_t n, uint32_t odd) {
+  CanonGeom g;
+  g.p = p; g.n = n; g.r5 = odd; g.M1 = 0; g.M2 = 0; g.C = 0;
+  g.logn2 = 0;
+  while ((uint64_t(odd) << g.logn2) < n) ++g.logn2;
+  return g;
+}
+size_t canon64_scratch_bytes(uint32_t n) {
+  const size_t nb = (size_t(n) + kBlockDigits - 1) / kBlockDigits;
+  return 2 * size_t(n) * 8 + (2 * nb + 16) * 4;
+}
+uint32_t* canon64_flags(uint32_t n, void* scratch) {
+  const size_t nb = (size_t(n) + kBlockDigits - 1) / kBlockDigits;
+  return reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(scratch) + 2 * size_t(n) * 8) + 2 * nb;
+}
+// digits: weakly carried u64 digits (any excess the three local passes remove: up to ~3 w bits); out: canonical digits, 2^p - 1 -> 0
+hipError_t canon64_launch(uint32_t p, uint32_t n, uint32_t odd, const uint64_t* digits, uint64_t* out, void* scratch, hipStream_t s) {
+  const CanonGeom g = geom64(p, n, odd);
+  const size_t nb = (size_t(n) + kBlockDigits - 1) / kBlockDigits;
+  uint64_t* A = static_cast<uint64_t*>(scratch);
+  uint32_t* agg = reinterpret_cast<uint32_t*>(A + 2 * size_t(n));
+  launch_pipeline<uint64_t>(g, digits, out, A, A + n, agg, agg + nb, agg + 2 * nb, s);
+  return hipGetLastError();
+}
+hipError_t canon64_compare(const uint64_t* a, const uint64_t* b, uint32_t n, uint32_t* diff_flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_compare<uint64_t>, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, diff_flag);
+  return hipGetLastError();
+}
+// one local carry pass (in -> out): digits of up to w + e bits come out below 2^w + 2^e
+hipError_t canon64_relax(uint32_t p, uint32_t n, uint32_t odd, const uint64_t* in, uint64_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_local<uint64_t>, dim3((n + 255) / 256), dim3(256), 0, s, geom64(p, n, odd), in, out);
+  return hipGetLastError();
+}
+hipError_t canon64_add_complement(uint32_t p, uint32_t n, uint32_t odd, uint64_t* dst, const uint64_t* canon, hipStream_t s) {
+  hipLaunchKernelGGL(k_add_complement<uint64_t>, dim3((n + 255) / 256), dim3(256), 0, s, geom64(p, n, odd), dst, canon);
   return hipGetLastError();
 }
 

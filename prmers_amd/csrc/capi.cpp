@@ -51,8 +51,8 @@ mi355::Engine* eng(mi355_engine_handle h) {
 }
 mi355::CrtEngine* crt(mi355_engine_handle h) { return hnd(h)->c; }   // nullptr for a Goldilocks handle
 
-// "crt", "crt:9", "crt:3:words=6291456", "crt:9:h2=5" ...
-struct CrtSpec { uint32_t odd = 1; size_t words = 0; std::string rest; };
+// "crt" / "crt:auto" (radix by the reference's policy, crt_auto_radix), "crt:9", "crt:3:words=6291456", "crt:9:h2=5" ...
+struct CrtSpec { uint32_t odd = 0; size_t words = 0; std::string rest; };   // odd 0: automatic
 bool parse_crt_spec(const char* spec, CrtSpec& out) {
   if (!spec || std::strncmp(spec, "crt", 3) != 0 || (spec[3] != 0 && spec[3] != ':')) return false;
   std::string s = spec[3] ? spec + 4 : "";
@@ -62,6 +62,7 @@ bool parse_crt_spec(const char* spec, CrtSpec& out) {
     const size_t e = s.find(':', pos);
     const std::string tok = s.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
     if (first && !tok.empty() && std::isdigit(static_cast<unsigned char>(tok[0]))) out.odd = uint32_t(std::stoul(tok));
+    else if (first && tok == "auto") out.odd = 0;
     else if (tok.rfind("words=", 0) == 0) out.words = std::stoull(tok.substr(6));
     else if (!tok.empty()) out.rest = tok;
     first = false;
@@ -69,6 +70,13 @@ bool parse_crt_spec(const char* spec, CrtSpec& out) {
     pos = e + 1;
   }
   return true;
+}
+// the radix of an automatic spec ("crt", "crt:auto", "crt:words=N": N decides when it is given)
+void settle_crt_radix(uint32_t exponent, CrtSpec& cs) {
+  if (cs.odd != 0) return;
+  if (cs.words) cs.odd = (cs.words % 9 == 0) ? 9u : (cs.words % 3 == 0) ? 3u : 1u;
+  else cs.odd = mi355::crt_auto_radix(exponent, nullptr);
+  if (cs.odd == 0) throw std::runtime_error("crt: no admissible transform size for this exponent");
 }
 
 }  // namespace
@@ -84,6 +92,7 @@ int mi355_engine_resolve_fft(uint32_t exponent, const char* fft_spec, char* outp
     std::string s;
     CrtSpec cs;
     if (parse_crt_spec(fft_spec, cs)) {
+      settle_crt_radix(exponent, cs);
       const size_t n = cs.words ? cs.words : mi355::crt_transform_size(exponent, cs.odd);
       if (!n) throw std::runtime_error("resolve_fft: no admissible crt transform size");
       s = "crt-hip:n=" + std::to_string(n) + ":odd=" + std::to_string(cs.odd);
@@ -101,7 +110,7 @@ mi355_engine_handle mi355_engine_create(uint32_t exponent, size_t register_count
   if (!guarded([&] {
         H = new Handle;
         CrtSpec cs;
-        if (parse_crt_spec(fft_spec, cs)) H->c = new mi355::CrtEngine(exponent, register_count, cs.odd, cs.words, int(device), cs.rest.empty() ? nullptr : cs.rest.c_str());
+        if (parse_crt_spec(fft_spec, cs)) { settle_crt_radix(exponent, cs); H->c = new mi355::CrtEngine(exponent, register_count, cs.odd, cs.words, int(device), cs.rest.empty() ? nullptr : cs.rest.c_str()); }
         else H->g = new mi355::Engine(exponent, register_count, int(device), verbose != 0, fft_spec);
       })) {
     delete H;

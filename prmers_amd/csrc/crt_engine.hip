@@ -380,6 +380,30 @@ size_t crt_transform_size(uint32_t p, uint32_t odd) {   // m2:479-503: smallest 
   return 0;
 }
 
+// Automatic choice between the stock power-of-two size and the prime-factor sizes, the reference's policy (README.md:888-926,
+// third_party/aevum/src/FFTConfig.cpp:425-520): radix 9 when the stock / PFA size ratio reaches 1.60, else radix 3 when it reaches 1.30,
+// else the stock plan.  With the size rule above the candidates below the stock 2^k are 9 2^(k-4) (ratio 1.778) and 3 2^(k-2) (1.333).
+// (The reference's exponent boundaries come from its measured bits-per-word tables, fftbpw.h, which admit ~39 bits per word where the
+// worst-case rule used here admits ~34: same policy, boundaries of this engine's own capacity rule; tests/test_host_logic.py.)
+uint32_t crt_auto_radix(uint32_t p, size_t* words) {
+  const size_t stock = crt_transform_size(p, 1), n3 = crt_transform_size(p, 3), n9 = crt_transform_size(p, 9);
+  uint32_t odd = 1;
+  size_t n = stock;
+  if (n9 && stock && double(stock) / double(n9) >= 1.60) { odd = 9; n = n9; }
+  else if (n3 && stock && double(stock) / double(n3) >= 1.30) { odd = 3; n = n3; }
+  else if (!stock) { if (n9) { odd = 9; n = n9; } else if (n3) { odd = 3; n = n3; } }
+  if (words) *words = n;
+  return n ? odd : 0;
+}
+
+// device-side canonical form for u64 digits in natural order (canon.hip)
+size_t canon64_scratch_bytes(uint32_t n);
+uint32_t* canon64_flags(uint32_t n, void* scratch);
+hipError_t canon64_launch(uint32_t p, uint32_t n, uint32_t odd, const uint64_t* digits, uint64_t* out, void* scratch, hipStream_t s);
+hipError_t canon64_compare(const uint64_t* a, const uint64_t* b, uint32_t n, uint32_t* diff_flag, hipStream_t s);
+hipError_t canon64_relax(uint32_t p, uint32_t n, uint32_t odd, const uint64_t* in, uint64_t* out, hipStream_t s);
+hipError_t canon64_add_complement(uint32_t p, uint32_t n, uint32_t odd, uint64_t* dst, const uint64_t* canon, hipStream_t s);
+
 struct CrtEngine::Impl {
   crt::Geom g;
   crt::Grid gr;
@@ -404,6 +428,13 @@ struct CrtEngine::Impl {
   F31::C *W1_31 = nullptr, *W2_31 = nullptr, *V31 = nullptr, *LO31 = nullptr, *HI31 = nullptr;
   hipEvent_t ev[kKernels + 1] = {};
   std::vector<uint8_t> width;
+  // device-side canonical form (canon.hip, SURVEY.md 8f N4 extended to this family): scratch + two outputs of n digits, allocated on first use
+  void* canon = nullptr;
+  uint64_t* canon_out[2] = {nullptr, nullptr};
+  bool host_carry = false;       // MI355_HOST_CARRY=1: the round-2 host paths (A/B tests)
+  // bits by which a register's digits may exceed their widths: 0 after a carry sweep, +1 per digit-wise addition; a transform needs
+  // log2(n) + 2 (w + excess) < 92 and relaxes the register first (one local carry pass) when that fails
+  std::vector<int> excess;
 };
 
 const char* CrtEngine::kernel_name(size_t k) {
@@ -506,6 +537,8 @@ CrtEngine::CrtEngine(uint32_t p, size_t reg_count, uint32_t odd, size_t n_forced
     im.width.resize(n);
     uint64_t prev = 0;
     for (size_t j = 0; j < n; ++j) { const uint64_t next = (uint64_t(p) * (j + 1) + n - 1) / n; im.width[j] = uint8_t(next - prev); prev = next; }
+    im.excess.assign(reg_count, 0);
+    { const char* hc = std::getenv("MI355_HOST_CARRY"); im.host_carry = hc && hc[0] == '1'; }
   } catch (...) {
     release();
     throw;
@@ -519,6 +552,7 @@ void CrtEngine::release() {
   if (im.stream) (void)hipStreamSynchronize(im.stream);
   for (auto& r : im.regs) for (void* q : {static_cast<void*>(r.x), static_cast<void*>(r.i61), static_cast<void*>(r.i31)}) if (q) (void)hipFree(q);
   if (im.scratch) (void)hipFree(im.scratch);
+  if (im.canon) (void)hipFree(im.canon);
   for (void* q : {static_cast<void*>(im.Z61), static_cast<void*>(im.Z31), static_cast<void*>(im.U61), static_cast<void*>(im.U31),
                   static_cast<void*>(im.w61), static_cast<void*>(im.w31), static_cast<void*>(im.carry), static_cast<void*>(im.residual),
                   static_cast<void*>(im.W1_61), static_cast<void*>(im.W2_61), static_cast<void*>(im.V61), static_cast<void*>(im.W1_31),
@@ -649,11 +683,51 @@ void CrtEngine::check_digits(size_t reg, const char* what) const {
   if (im_->regs[reg].image) throw std::runtime_error(std::string(what) + ": register holds a multiplicand image, not a residue");
 }
 
+// Headroom of the transform: the convolution sums stay below M61 M31 ~ 2^92 while log2(n) + 2 (w + excess) < 92 (the size rule is that
+// bound at excess 0).  A register that has been through digit-wise additions is relaxed first when it would not fit: one local carry
+// pass (canon.hip k_local) brings digits of w + e bits below 2^w + 2^e.
+void CrtEngine::ensure_headroom(size_t reg) {
+  Impl& im = *im_;
+  const int e = im.excess[reg];
+  if (e == 0) return;
+  const double bits = std::log2(double(im.g.n)) + 2.0 * (double(im.g.q) + 1.0 + double(e));
+  if (bits < 92.0 && e < 8) return;
+  chk(canon64_relax(im.g.p, im.g.n, im.gr.odd, im.regs[reg].x, im.scratch, im.stream), "relax");
+  std::swap(im.regs[reg].x, im.scratch);
+  im.excess[reg] = 0;
+}
+
+// canonical digits of `reg` on the device (strong carry with wrap-around, 2^p - 1 -> 0 and flag [0]); slot 0 / 1
+uint64_t* CrtEngine::canon_digits(size_t reg, int slot) {
+  Impl& im = *im_;
+  chk(hipSetDevice(im.device), "hipSetDevice");
+  if (!im.canon) {
+    const size_t sb = (canon64_scratch_bytes(im.g.n) + 255) & ~size_t(255);
+    chk(hipMalloc(&im.canon, sb + 2 * size_t(im.g.n) * 8), "hipMalloc");
+    im.canon_out[0] = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(im.canon) + sb);
+    im.canon_out[1] = im.canon_out[0] + im.g.n;
+    chk(hipMemsetAsync(canon64_flags(im.g.n, im.canon), 0, 16 * 4, im.stream), "memset");
+  }
+  chk(canon64_launch(im.g.p, im.g.n, im.gr.odd, im.regs[reg].x, im.canon_out[slot], im.canon, im.stream), "canon");
+  return im.canon_out[slot];
+}
+// flags: [0] all ones, [1] a digit too wide for the 0/1 chain (fall back to the host carry), [2] compare differs; cleared for the next use
+bool CrtEngine::canon_flags_ok(uint32_t (&flags)[4]) {
+  Impl& im = *im_;
+  uint32_t* df = canon64_flags(im.g.n, im.canon);
+  chk(hipMemcpyAsync(flags, df, 16, hipMemcpyDeviceToHost, im.stream), "copy");
+  chk(hipMemsetAsync(df, 0, 16 * 4, im.stream), "memset");
+  chk(hipStreamSynchronize(im.stream), "sync");
+  return flags[1] == 0;
+}
+
 void CrtEngine::square_mul(size_t reg, uint32_t a) {
   check_digits(reg, "square_mul");
   if (a == 0) throw std::runtime_error("square_mul: factor must be >= 1");
   chk(hipSetDevice(im_->device), "hipSetDevice");
+  ensure_headroom(reg);
   launch_transform(reg, 0, 0, a, false);
+  im_->excess[reg] = 0;
 }
 
 // dst <- the transformed image of src (engine::set_multiplicand, engine.h:53); dst may be src
@@ -667,6 +741,7 @@ void CrtEngine::set_multiplicand(size_t dst, size_t src) {
     chk(hipMalloc(reinterpret_cast<void**>(&d.i61), size_t(im.gr.odd) * im.gr.h * 16), "hipMalloc");
     chk(hipMalloc(reinterpret_cast<void**>(&d.i31), size_t(im.gr.odd) * im.gr.h * 8), "hipMalloc");
   }
+  ensure_headroom(src);
   launch_transform(src, 1, dst, 1, false);
   d.image = true;
 }
@@ -678,7 +753,9 @@ void CrtEngine::mul(size_t dst, size_t src, uint32_t a) {
   if (src >= im.regs.size() || !im.regs[src].image) throw std::runtime_error("mul: the source register is not a multiplicand (call set_multiplicand first)");
   if (a == 0) throw std::runtime_error("mul: factor must be >= 1");
   chk(hipSetDevice(im.device), "hipSetDevice");
+  ensure_headroom(dst);
   launch_transform(dst, 2, src, a, false);
+  im.excess[dst] = 0;
 }
 
 void CrtEngine::copy(size_t dst, size_t src) {
@@ -696,6 +773,7 @@ void CrtEngine::copy(size_t dst, size_t src) {
     chk(hipMemcpyAsync(d.i31, r.i31, size_t(im.gr.odd) * im.gr.h * 8, hipMemcpyDeviceToDevice, im.stream), "copy");
   } else {
     chk(hipMemcpyAsync(d.x, r.x, size_t(im.g.n) * 8, hipMemcpyDeviceToDevice, im.stream), "copy");
+    im.excess[dst] = im.excess[src];
   }
   d.image = r.image;
 }
@@ -706,19 +784,30 @@ void CrtEngine::add(size_t dst, size_t src) {
   check_digits(dst, "add"); check_digits(src, "add");
   chk(hipSetDevice(im.device), "hipSetDevice");
   hipLaunchKernelGGL(crt::k_add_digits, dim3((im.g.n + 255) / 256), dim3(256), 0, im.stream, im.regs[dst].x, im.regs[src].x, im.g.n);
+  im.excess[dst] = std::max(im.excess[dst], im.excess[src]) + 1;
+  if (im.excess[dst] >= 8) ensure_headroom(dst);   // repeated additions without a transform in between
 }
 
-// dst <- dst - src = dst + (2^p - 1 - src): the complement of the canonical digits of src (read back: LL-safe's rare operation)
+// the canonical digits of `src` on the device (slot 1), through the host when the device chain reports a digit too wide for it
+const uint64_t* CrtEngine::canonical_on_device(size_t src) {
+  Impl& im = *im_;
+  const uint64_t* c = canon_digits(src, 1);
+  uint32_t flags[4];
+  if (canon_flags_ok(flags) && !im.host_carry) return c;
+  std::vector<uint64_t> d(im.g.n);
+  get_digits_host(src, d.data(), im.g.n);
+  chk(hipMemcpy(im.canon_out[1], d.data(), size_t(im.g.n) * 8, hipMemcpyHostToDevice), "copy");
+  return im.canon_out[1];
+}
+
+// dst <- dst - src = dst + (2^p - 1 - src): the digit-wise complement of the canonical form of src, taken on the device
 void CrtEngine::sub_reg(size_t dst, size_t src) {
   Impl& im = *im_;
   check_digits(dst, "sub_reg"); check_digits(src, "sub_reg");
-  const size_t n = im.g.n;
-  std::vector<uint64_t> d(n);
-  get_digits(src, d.data(), n, true);
-  for (size_t j = 0; j < n; ++j) d[j] = ((uint64_t(1) << im.width[j]) - 1) - d[j];
-  chk(hipMemcpy(im.w61, d.data(), n * 8, hipMemcpyHostToDevice), "copy");      // the carry sweep's input buffer is free between squarings
-  hipLaunchKernelGGL(crt::k_add_digits, dim3((im.g.n + 255) / 256), dim3(256), 0, im.stream, im.regs[dst].x, im.w61, im.g.n);
-  chk(hipStreamSynchronize(im.stream), "sync");
+  const uint64_t* c = canonical_on_device(src);
+  chk(canon64_add_complement(im.g.p, im.g.n, im.gr.odd, im.regs[dst].x, c, im.stream), "sub_reg");
+  im.excess[dst] = im.excess[dst] + 1;
+  if (im.excess[dst] >= 8) ensure_headroom(dst);
 }
 
 // sum -> sum_out (and sum_copy), difference -> diff_out (and diff_copy); -1: not wanted.  a and b may be among the outputs.
@@ -734,13 +823,12 @@ void CrtEngine::addsub(long sum_out, long sum_copy, long diff_out, long diff_cop
   chk(hipSetDevice(im.device), "hipSetDevice");
   const size_t n = im.g.n, bytes = n * 8;
   const dim3 grid((im.g.n + 255) / 256), block(256);
-  // scratch = a + (2^p - 1 - b): the complement of the canonical digits of b (a read-back, as in sub_reg), before anything is overwritten
+  // scratch = a + (2^p - 1 - b): the complement of the canonical digits of b (taken on the device, as in sub_reg), before anything is overwritten
+  const int ea = im.excess[a], eb = im.excess[b];
   if (diff_out >= 0) {
-    std::vector<uint64_t> d(n);
-    get_digits(b, d.data(), n, true);
-    for (size_t j = 0; j < n; ++j) d[j] = ((uint64_t(1) << im.width[j]) - 1) - d[j];
-    chk(hipMemcpy(im.scratch, d.data(), bytes, hipMemcpyHostToDevice), "copy");
-    hipLaunchKernelGGL(crt::k_add_digits, grid, block, 0, im.stream, im.scratch, im.regs[a].x, im.g.n);
+    const uint64_t* c = canonical_on_device(b);
+    chk(hipMemcpyAsync(im.scratch, im.regs[a].x, bytes, hipMemcpyDeviceToDevice, im.stream), "copy");
+    chk(canon64_add_complement(im.g.p, im.g.n, im.gr.odd, im.scratch, c, im.stream), "addsub");
   }
   if (sum_out >= 0) {
     if (size_t(sum_out) == b) {   // b + a
@@ -749,15 +837,14 @@ void CrtEngine::addsub(long sum_out, long sum_copy, long diff_out, long diff_cop
       if (size_t(sum_out) != a) chk(hipMemcpyAsync(im.regs[sum_out].x, im.regs[a].x, bytes, hipMemcpyDeviceToDevice, im.stream), "copy");
       hipLaunchKernelGGL(crt::k_add_digits, grid, block, 0, im.stream, im.regs[sum_out].x, im.regs[b].x, im.g.n);
     }
-    im.regs[sum_out].image = false;
-    if (sum_copy >= 0) { chk(hipMemcpyAsync(im.regs[sum_copy].x, im.regs[sum_out].x, bytes, hipMemcpyDeviceToDevice, im.stream), "copy"); im.regs[sum_copy].image = false; }
+    im.regs[sum_out].image = false; im.excess[sum_out] = std::max(ea, eb) + 1;
+    if (sum_copy >= 0) { chk(hipMemcpyAsync(im.regs[sum_copy].x, im.regs[sum_out].x, bytes, hipMemcpyDeviceToDevice, im.stream), "copy"); im.regs[sum_copy].image = false; im.excess[sum_copy] = im.excess[sum_out]; }
   }
   if (diff_out >= 0) {
     chk(hipMemcpyAsync(im.regs[diff_out].x, im.scratch, bytes, hipMemcpyDeviceToDevice, im.stream), "copy");
-    im.regs[diff_out].image = false;
-    if (diff_copy >= 0) { chk(hipMemcpyAsync(im.regs[diff_copy].x, im.scratch, bytes, hipMemcpyDeviceToDevice, im.stream), "copy"); im.regs[diff_copy].image = false; }
+    im.regs[diff_out].image = false; im.excess[diff_out] = ea + 1;
+    if (diff_copy >= 0) { chk(hipMemcpyAsync(im.regs[diff_copy].x, im.scratch, bytes, hipMemcpyDeviceToDevice, im.stream), "copy"); im.regs[diff_copy].image = false; im.excess[diff_copy] = ea + 1; }
   }
-  chk(hipStreamSynchronize(im.stream), "sync");
 }
 void CrtEngine::mul_add(size_t dst, size_t mul_src, size_t add_src, uint32_t f) { mul(dst, mul_src, f); add(dst, add_src); }
 void CrtEngine::square_mul_copy(size_t src, size_t dst_copy, uint32_t f) { square_mul(src, f); copy(dst_copy, src); }
@@ -769,7 +856,7 @@ void CrtEngine::set_u32(size_t reg, uint32_t a) {
   chk(hipSetDevice(im.device), "hipSetDevice");
   chk(hipMemsetAsync(im.regs[reg].x, 0, size_t(im.g.n) * 8, im.stream), "memset");
   if (a) hipLaunchKernelGGL(crt::k_set_small, dim3(1), dim3(1), 0, im.stream, im.g, im.regs[reg].x, a);
-  im.regs[reg].image = false;
+  im.regs[reg].image = false; im.excess[reg] = 0;
 }
 void CrtEngine::sub_u32(size_t reg, uint32_t a) {
   Impl& im = *im_;
@@ -787,16 +874,38 @@ void CrtEngine::set_digits(size_t reg, const uint64_t* d, size_t count) {
   chk(hipStreamSynchronize(im.stream), "sync");
   chk(hipMemcpy(im.regs[reg].x, d, count * 8, hipMemcpyHostToDevice), "copy");
   im.regs[reg].image = false;
+  int e = 0;   // callers may hand over digits wider than their slots (weakly carried vectors)
+  for (size_t j = 0; j < count; ++j) { const int bits = d[j] ? 64 - __builtin_clzll(d[j]) : 0; e = std::max(e, bits - int(im.width[j])); }
+  im.excess[reg] = e;
 }
 
-// digits as they are on the device (weakly carried) or canonical: strong carry with wrap-around, 2^p - 1 stays all ones
+// digits as they are on the device (weakly carried) or canonical: strong carry with wrap-around, 2^p - 1 stays all ones.
+// The canonical form is made on the device (canon.hip); MI355_HOST_CARRY=1 or a device chain that reports an over-wide digit use the
+// host loop below (the reference's way: engine_gpu.h:1534-1561).
 void CrtEngine::get_digits(size_t reg, uint64_t* d, size_t count, bool canonical) {
   Impl& im = *im_;
   check_digits(reg, "get_digits");
   if (count != im.g.n) throw std::runtime_error("get_digits: wrong digit count");
+  if (!canonical) {
+    sync();
+    chk(hipMemcpy(d, im.regs[reg].x, count * 8, hipMemcpyDeviceToHost), "copy");
+    return;
+  }
+  if (!im.host_carry) {
+    const uint64_t* c = canon_digits(reg, 0);
+    chk(hipMemcpyAsync(d, c, count * 8, hipMemcpyDeviceToHost, im.stream), "copy");
+    uint32_t flags[4];
+    if (canon_flags_ok(flags)) {
+      if (flags[0]) for (size_t j = 0; j < count; ++j) d[j] = (uint64_t(1) << im.width[j]) - 1;
+      return;
+    }
+  }
+  get_digits_host(reg, d, count);
+}
+void CrtEngine::get_digits_host(size_t reg, uint64_t* d, size_t count) {
+  Impl& im = *im_;
   sync();
   chk(hipMemcpy(d, im.regs[reg].x, count * 8, hipMemcpyDeviceToHost), "copy");
-  if (!canonical) return;
   uint64_t carry = 0;
   for (int lap = 0; lap < 4; ++lap) {
     for (size_t j = 0; j < count; ++j) {
@@ -866,14 +975,41 @@ void CrtEngine::set_words(size_t reg, const uint32_t* w, size_t count) {
   }
   set_digits(reg, d.data(), n);
 }
+// the low 64 bits of the canonical residue: canonical form on the device, the first digits cross PCIe
 uint64_t CrtEngine::res64(size_t reg) {
-  std::vector<uint32_t> w((size_t(im_->g.p) + 31) / 32 + 2, 0);
+  Impl& im = *im_;
+  check_digits(reg, "res64");
+  if (!im.host_carry) {
+    const uint64_t* c = canon_digits(reg, 0);
+    const size_t have = std::min<size_t>(im.g.n, 8);     // widths are at least 15 bits here (constructor): 8 digits hold more than 64 bits
+    uint64_t head[8];
+    chk(hipMemcpyAsync(head, c, have * 8, hipMemcpyDeviceToHost, im.stream), "copy");
+    uint32_t flags[4];
+    if (canon_flags_ok(flags)) {
+      if (flags[0]) return 0;                             // 2^p - 1 = 0
+      unsigned __int128 r = 0; unsigned sh = 0;
+      for (size_t k = 0; k < have && sh < 64; ++k) { r |= (unsigned __int128)head[k] << sh; sh += im.width[k]; }
+      if (size_t(im.g.p) < 64) r &= (((unsigned __int128)1) << im.g.p) - 1;
+      return uint64_t(r);
+    }
+  }
+  std::vector<uint32_t> w((size_t(im.g.p) + 31) / 32 + 2, 0);
   get_words(reg, w.data(), w.size());
   return uint64_t(w[0]) | (uint64_t(w[1]) << 32);
 }
-// same value mod 2^p - 1 (engine::is_equal, engine.h:148): canonical words on the host (two read-backs: a Gerbicz check, not the loop)
+// same value mod 2^p - 1 (engine::is_equal, engine.h:148): both canonical forms and the comparison on the device, 16 bytes cross PCIe
+// (the reference reads both registers back: engine.h:148-157)
 bool CrtEngine::equal(size_t a, size_t b) {
-  const size_t need = (size_t(im_->g.p) + 31) / 32;
+  Impl& im = *im_;
+  check_digits(a, "is_equal"); check_digits(b, "is_equal");
+  if (!im.host_carry) {
+    const uint64_t* ca = canon_digits(a, 0);
+    const uint64_t* cb = canon_digits(b, 1);
+    chk(canon64_compare(ca, cb, im.g.n, canon64_flags(im.g.n, im.canon) + 2, im.stream), "compare");
+    uint32_t flags[4];
+    if (canon_flags_ok(flags)) return flags[2] == 0;      // (2^p - 1 is written as 0 by both, so 0 == 2^p - 1 holds)
+  }
+  const size_t need = (size_t(im.g.p) + 31) / 32;
   std::vector<uint32_t> wa(need), wb(need);
   get_words(a, wa.data(), need); get_words(b, wb.data(), need);
   return wa == wb;
@@ -910,6 +1046,9 @@ void CrtEngine::set_data(size_t dst, const void* data, size_t size) {
     chk(hipMemcpy(r.i61, in, slots * 16, hipMemcpyHostToDevice), "copy"); chk(hipMemcpy(r.i31, in + slots * 16, slots * 8, hipMemcpyHostToDevice), "copy");
   } else {
     chk(hipMemcpy(r.x, in, n * 8, hipMemcpyHostToDevice), "copy");
+    int e = 0;   // the image holds weakly carried digits, possibly after additions: measure what it needs
+    for (size_t j = 0; j < n; ++j) { uint64_t v; std::memcpy(&v, in + j * 8, 8); const int bits = v ? 64 - __builtin_clzll(v) : 0; e = std::max(e, bits - int(im.width[j])); }
+    im.excess[dst] = e;
   }
   r.image = tag == 1;
 }

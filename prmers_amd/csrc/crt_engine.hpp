@@ -11,6 +11,7 @@
 namespace mi355 {
 
 size_t crt_transform_size(uint32_t p, uint32_t odd);
+uint32_t crt_auto_radix(uint32_t p, size_t* words);   // 1, 3 or 9 by the reference's stock / PFA size-ratio gates (0: no admissible size)
 
 class CrtEngine {
  public:
@@ -65,6 +66,11 @@ class CrtEngine {
   Impl* im_;
   void release();
   void check_digits(size_t reg, const char* what) const;
+  void ensure_headroom(size_t reg);                       // relax a register whose additions would overflow the next transform
+  uint64_t* canon_digits(size_t reg, int slot);           // device-side canonical form (canon.hip), slot 0 / 1
+  bool canon_flags_ok(uint32_t (&flags)[4]);
+  const uint64_t* canonical_on_device(size_t src);        // canonical digits of src in device memory (slot 1)
+  void get_digits_host(size_t reg, uint64_t* d, size_t count);   // read-back + host carry (fallback, MI355_HOST_CARRY=1)
   void launch_transform(size_t reg, int mode, size_t other, uint32_t a, bool timed);
 };
 

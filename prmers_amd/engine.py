@@ -270,9 +270,10 @@ class CrtEngine(Engine):
     Digits are plain u64 values here (widths reach 39 bits).  No CPU fallback."""
 
     def __init__(self, p, odd=1, n=0, device=0, plan=None, reg_count=4):
-        spec = "crt:%d" % odd + (":words=%d" % n if n else "") + (":" + plan if plan else "")
+        """odd = None / "auto": radix 9, 3 or none by the reference's stock / PFA size-ratio gates (README.md:888-926)"""
+        spec = ("crt:auto" if odd in (None, "auto") else "crt:%d" % odd) + (":words=%d" % n if n else "") + (":" + plan if plan else "")
         Engine.__init__(self, p, reg_count, device, False, spec)
-        self.odd = odd
+        self.odd = int(self.describe().split("odd=")[1].split(":")[0]) if odd in (None, "auto") else odd
 
     def raw_digits(self, src=0):
         """the engine's own digits: plain values in base 2^width_j, canonical (widths reach 39 bits)"""

@@ -206,6 +206,108 @@ def test_checkpoints_and_raw_images_on_the_crt_engine(tmp_path):
         assert "Resuming from a checkpoint." in msgs and r["is_prime"] and r["complete"] and r["gerbicz_errors"] == 0
 
 
+def _max_exponent(n):
+    import math
+    lo, hi = n, 60 * n
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if math.log2(n) + 2.0 * (mid / n + 1.0) < 92.0:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo
+
+
+@pytest.mark.parametrize("odd,n", [(9, 9 << 9), (3, 3 << 12), (1, 1 << 14)])
+def test_additions_at_the_top_of_a_size_range_keep_their_headroom(odd, n):
+    """digit-wise additions leave digits above their widths; at the largest exponent a size admits the next transform has no
+    bit to spare, so the engine must relax such a register first.  (x + 2 y)^2, (x - y) y ... against Python integers."""
+    p = _max_exponent(n)
+    if p % 2 == 0:
+        p -= 1
+    M = (1 << p) - 1
+    rng = np.random.default_rng(p)
+    x, y = (int.from_bytes(rng.bytes((p + 7) // 8), "little") % M for _ in range(2))
+    with CrtEngine(p, odd, n, reg_count=6) as e:
+        assert e.n == n
+        e.set_int(0, x); e.set_int(1, y)
+        e.add(0, 1); e.add(0, 1)                  # x + 2 y: two excess bits
+        e.copy(2, 0)
+        e.square_mul(0)
+        assert e.get_int(0) == pow(x + 2 * y, 2, M)
+        e.set_multiplicand(3, 2)                  # a multiplicand of a register that went through additions
+        e.mul(1, 3, 3)
+        assert e.get_int(1) == 3 * y * (x + 2 * y) % M
+        e.set_int(4, x); e.set_int(5, y)
+        for _ in range(20):                        # repeated additions without a transform in between
+            e.add(4, 5)
+        e.sub_reg(4, 5)
+        e.square_mul(4)
+        assert e.get_int(4) == pow(x + 19 * y, 2, M)
+        e.set_int(4, x); e.set_int(5, y)
+        e.addsub(2, 3, 4, 5)                       # sum -> 2, difference -> 3
+        e.square_mul(2); e.square_mul(3)
+        assert e.get_int(2) == pow(x + y, 2, M) and e.get_int(3) == pow(x - y, 2, M)
+
+
+def test_device_side_canonical_form_on_the_crt_family(monkeypatch):
+    """SURVEY.md 8f N4 on this family: is_equal / res64 / digits / sub_reg canonicalise on the device (canon.hip with u64 digits);
+    the host path of round 2 (MI355_HOST_CARRY=1) and Python integers are the checkers: all ones, carry chains through every digit,
+    digits far above their widths, 0 == 2^p - 1."""
+    p, odd = 216091, 9
+    M = (1 << p) - 1
+    from prmers_amd import CrtEngine as E
+    with E(p, odd) as e:
+        n = e.n
+        j = np.arange(n + 1, dtype=np.uint64)
+        ceil = (j * np.uint64(p) + np.uint64(n - 1)) // np.uint64(n)
+        w = (ceil[1:] - ceil[:-1]).astype(np.uint64)
+        ones = (np.uint64(1) << w) - np.uint64(1)
+        rng = np.random.default_rng(7)
+
+        def value(d):
+            v, sh = 0, 0
+            for dj, wj in zip(d.tolist(), w.tolist()):
+                v += int(dj) << sh
+                sh += int(wj)
+            return v % M
+        cases = {"all_ones": ones.copy(), "ones_plus_one": ones.copy(), "chain": ones.copy(), "wide": rng.integers(0, 1 << 61, n, dtype=np.uint64),
+                 "random": rng.integers(0, 1 << 62, n, dtype=np.uint64) & ones}
+        cases["ones_plus_one"][0] += np.uint64(1)              # 2^p: the carry runs through every digit and wraps to 1
+        cases["chain"][5] += np.uint64(3)
+        for name, d in cases.items():
+            e.set_digits(0, d)
+            want = value(d)
+            assert e.get_int(0) == want, name
+            assert e.res64(0) == want & (2**64 - 1), name
+            e.set_int(1, want)
+            assert e.is_equal(0, 1) and e.is_equal(1, 0), name
+            e.set_int(2, (want + 1) % M)
+            assert not e.is_equal(0, 2), name
+            e.set_int(3, 12345); e.sub_reg(3, 0)
+            assert e.get_int(3) == (12345 - want) % M, name
+        e.set_digits(0, cases["all_ones"]); e.set(1, 0)
+        assert e.is_equal(0, 1) and e.res64(0) == 0            # 2^p - 1 == 0
+    monkeypatch.setenv("MI355_HOST_CARRY", "1")
+    with E(p, odd) as h:
+        for name, d in cases.items():
+            h.set_digits(0, d)
+            assert h.get_int(0) == value(d) and h.res64(0) == value(d) & (2**64 - 1), name
+
+
+def test_automatic_radix_behind_the_plain_crt_spec():
+    """fft_spec "crt" / "crt:auto": radix by the reference's size-ratio gates (README.md:888-926)"""
+    for p, odd, n in [(9941, 1, 256), (86243, 9, 2304), (216091, 3, 6144)]:
+        from prmers_amd import resolve_plan
+        assert resolve_plan(p, "crt") == "crt-hip:n=%d:odd=%d" % (n, odd), resolve_plan(p, "crt")
+        with CrtEngine(p, None) as e:
+            assert (e.odd, e.n) == (odd, n)
+            e.set(0, 3)
+            for _ in range(40):
+                e.square_mul(0)
+            assert e.get_int(0) == pow(3, 1 << 40, (1 << p) - 1)
+
+
 def test_sizes_with_too_few_bits_per_word_are_refused():
     from prmers_amd import EngineError
     with pytest.raises(EngineError, match="bits per word"):

@@ -374,3 +374,51 @@ def test_cpp_driver_worktodo_checkpoint_proof_and_json_on_gpu(tmp_path):
     assert (tmp_path / "100003" / "proof" / "25001").stat().st_size == 4 + 4 * ((100003 + 31) // 32)
     o3 = run("-worktodo", str(wt))
     assert "probably prime" in o3.stdout and wt.read_text() == ""
+
+
+def test_automatic_pfa_radix_follows_the_reference_policy_at_the_exact_boundaries():
+    """fft_spec "crt" picks radix 9 / 3 / none by the reference's stock-to-PFA size-ratio gates (1.60 / 1.30, README.md:888-926).  The
+    capacity of a size is this engine's own worst-case rule (log2 n + 2 (p/n + 1) < 92; the reference's boundaries come from its measured
+    bits-per-word tables and lie ~15 % higher), so the table is checked row by row at OUR exact boundaries: the largest exponent a size
+    admits selects exactly the (radix, words) pair of the reference's row, the next exponent moves on to the next larger size."""
+    import math
+    from prmers_amd import resolve_plan
+
+    def admits(n, p):
+        return n <= p and math.log2(n) + 2.0 * (p / n + 1.0) < 92.0
+
+    def max_exponent(n):
+        lo, hi = n, 60 * n
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if admits(n, mid):
+                lo = mid
+            else:
+                hi = mid - 1
+        return lo
+
+    def auto(p):
+        m = re.fullmatch(r"crt-hip:n=(\d+):odd=(\d+)", resolve_plan(p, "crt"))
+        return int(m.group(2)), int(m.group(1))
+
+    # (radix, words) of every row of README.md:907-922 that fits 32-bit exponents, in the table's order
+    rows = [(3, 393216), (3, 786432), (9, 1179648), (3, 1572864), (9, 2359296), (3, 3145728), (9, 4718592), (3, 6291456), (9, 9437184),
+            (3, 12582912), (9, 18874368), (3, 25165824), (9, 37748736), (9, 75497472)]
+    sizes = sorted(set([1 << k for k in range(10, 28)] + [3 << k for k in range(8, 26)] + [9 << k for k in range(7, 25)]))
+    for odd, n in rows:
+        top = max_exponent(n)
+        if top >= 2**32:
+            continue
+        assert auto(top) == (odd, n), (odd, n, top)
+        bigger = min(x for x in sizes if x > n)
+        if top + 1 < 2**32 and max_exponent(bigger) < 2**32:
+            assert auto(top + 1)[1] == bigger, (n, top + 1)
+    # in between the gates keep the stock plan: a power of two is chosen exactly when it is the smallest admissible size of the three families
+    for k in (17, 20, 23):
+        n = 1 << k
+        assert auto(max_exponent(n)) == (1, n)
+        below = max(x for x in sizes if x < n)          # 3 * 2^(k-2), the next smaller size
+        assert auto(max_exponent(below) + 1) == (1, n) and below == 3 * n // 4
+    # BASELINE configs[3]: the automatic plan of p = 205271257 is the radix-3 size of the reference's own table row (README.md:916)
+    assert auto(205271257) == (3, 6291456)
+    assert resolve_plan(205271257, "crt:9") == "crt-hip:n=9437184:odd=9" and resolve_plan(205271257, "crt:auto") == "crt-hip:n=6291456:odd=3"

@@ -149,3 +149,42 @@ def test_launcher_command_line_dry_run(tmp_path):
     assert out.returncode == 0, out.stderr
     shards = [json.loads(l) for l in out.stdout.splitlines()]
     assert [e["exponent"] for e in shards[0]["entries"]] == [127, 607] and [e["exponent"] for e in shards[1]["entries"]] == [521, 1001]
+
+
+def _torchrun(tmp_path, *args, timeout=300):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_stub_entry.py"), *args]
+    return subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="1"))
+
+
+def test_the_torchrun_command_line_of_the_launcher_end_to_end(tmp_path):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... -m prmers_amd.launch --worktodo ...` with the
+    engine replaced by the oracle (tests/dist_stub_entry.py): rendezvous, sharding, reductions, gather, the result file with real fft lengths"""
+    wt = tmp_path / "worktodo.txt"
+    wt.write_text("\n".join(WORKTODO) + "\n")
+    out = _torchrun(tmp_path, "launch", "--worktodo", str(wt), "--backend", "gloo", "--checklevel", "1", "--results", str(tmp_path / "results.json.txt"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    summary = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert summary["status"]["all_ok"] == 1 and summary["status"]["iterations"] == 127 + 521 + 605 + 1001
+    assert sorted((r["exponent"], r["rank"], r["is_prime"]) for r in summary["results"]) == [(127, 0, True), (521, 1, True), (607, 0, True), (1001, 1, False)]
+    lines = [json.loads(l) for l in (tmp_path / "results.json.txt").read_text().splitlines()]
+    assert sorted(l["exponent"] for l in lines) == [127, 521, 607, 1001] and all(l["fft-length"] > 0 for l in lines)
+
+
+def test_the_torchrun_command_line_of_the_bench_end_to_end(tmp_path):
+    """`python -m torch.distributed.run ... bench.py --gpus 2 --steps K --warmup W` with a timing stub for the engine: one JSON line from
+    rank 0, whole-job value, max-over-ranks time, one exponent per rank listed"""
+    out = _torchrun(tmp_path, "bench", "--gpus", "2", "--steps", "50", "--warmup", "5", "--dist-backend", "gloo", "--preheat-seconds", "0")
+    assert out.returncode == 0, out.stdout + out.stderr
+    js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(js) == 1
+    d = json.loads(js[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 50 and d["warmup"] == 5 and d["scaling"] == "weak" and d["unit"] == "iter/s"
+    assert abs(d["value"] - 2 * 50 / (d["ms_per_step"] * 50e-3)) < 1e-2 * d["value"]
+    ranks = d["config"]["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["exponent"] for r in ranks] == [136279841, 136279879]
+    assert max(r["ms_per_step"] for r in ranks) <= d["ms_per_step"] + 1e-6
+    assert d["config"]["status_reduction_backend"] == "gloo" and "cpu_baseline" not in d
