@@ -729,7 +729,7 @@ void Engine::probe(int kind, int grid_mult, int extra_lds, int boost_pct, size_t
   {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_));
-    const size_t per_cu = (v2_lds_bytes() + size_t(extra_lds)) * 2 <= size_t(160) * 1024 ? 2 : 1;
+    const size_t per_cu = extra_lds >= 20 * 1024 ? 1 : 2;
     const size_t slots = per_cu * size_t(prop.multiProcessorCount);
     const uint32_t from = (boost_pct > 0 && grid > slots) ? uint32_t(grid - slots * size_t(boost_pct) / 100) : ~0u;
     d.boost_rows = d.boost_tiles = from;

@@ -705,8 +705,20 @@ __global__ void __launch_bounds__(512, 4) k3_cols_ext(DevPlan pl, const uint64_t
 // ---------------------------------------------------------------------------------------------
 namespace v5 {
 constexpr uint32_t kThreads = 640, kTile = 5120, kM1 = 1280;
-constexpr uint32_t kLdsBytes = (kTile + kTile / 32 + 8) * 8;
+// Launched with 768 threads: twelve waves spread evenly over the four SIMDs of a CU, the last two leave at once.  A work-group of ten waves
+// (3 + 3 + 2 + 2) is not placed next to a resident one for up to 17 us after a slot has become free (profiles/r03_probe_c4.md: 44 % of
+// the dispatches of a launch, a CU then runs one group for half of its time); twelve are placed within 2 us like the 512-thread groups.
+constexpr uint32_t kLaunchThreads = 768;
+constexpr uint32_t kPlaneWords = kTile + kTile / 32 + 8;
+// the exchange plane, then a copy of the omega_1280 table (10 KiB): the seams of this shape are table multiplications and their roots
+// come out of LDS (~100 cycles) instead of L2 (several hundred, exposed at every stage)
+constexpr uint32_t kLdsBytes = (kPlaneWords + kM1) * 8;
 __device__ __forceinline__ uint32_t ph(uint32_t i) { return i + (i >> 5); }
+__device__ __forceinline__ const uint64_t* stage_roots(const DevPlan& pl, uint64_t* X) {
+  uint64_t* R = X + kPlaneWords;
+  for (uint32_t i = threadIdx.x; i < kM1; i += kThreads) R[i] = pl.UT1[i];
+  return R;   // visible after the first barrier of the first exchange
+}
 
 // write 8 (or 10) values to element ids wi[], read ids ri[]; one plane after the other
 template <int NW, int NR, class WI, class RI>
@@ -742,12 +754,15 @@ __device__ __forceinline__ void dft5p(v2::P2 (&x)[5], const uint64_t (&c5)[4], b
 
 __device__ __forceinline__ uint32_t brev8(uint32_t k) { return __brev(k) >> 24; }
 
-__global__ void __launch_bounds__(640, 2) k1_cols5(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in, uint32_t sub,
+__global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in, uint32_t sub,
                                                    uint64_t* __restrict__ Wout) {
   using v2::P2;
+  if (threadIdx.x >= kThreads) return;   // the two padding waves (kLaunchThreads): ended waves do not count at a barrier
   uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
-  const uint32_t t = threadIdx.x, T = blockIdx.x;
+  const uint32_t t = threadIdx.x, T = PROBE_BLOCK(pl);
   v2::boost_if_late(pl.boost_tiles);
+  PROBE_BEGIN(pl)
+  const uint64_t* __restrict__ UT = stage_roots(pl, X);
   // ---- L: the thread's two runs ----
   P2 x[8];
   {
@@ -784,7 +799,7 @@ __global__ void __launch_bounds__(640, 2) k1_cols5(DevPlan pl, const uint32_t* _
       P2 z[5] = {y[5 * q], y[5 * q + 1], y[5 * q + 2], y[5 * q + 3], y[5 * q + 4]};
       dft5p(z, pl.W5c, false);
 #pragma unroll
-      for (int k0 = 1; k0 < 5; ++k0) z[k0] = v2::p2_mul(z[k0], pl.UT1[r * k0]);
+      for (int k0 = 1; k0 < 5; ++k0) z[k0] = v2::p2_mul(z[k0], UT[r * k0]);
 #pragma unroll
       for (int k0 = 0; k0 < 5; ++k0) y[5 * q + k0] = z[k0];
     }
@@ -803,7 +818,7 @@ __global__ void __launch_bounds__(640, 2) k1_cols5(DevPlan pl, const uint32_t* _
     const uint32_t rr = 8 * e2 + e3;
 #pragma unroll
     for (int k1 = 1; k1 < 4; ++k1) {
-      const uint64_t w = pl.UT1[5 * k1 * rr];   // omega_256 = omega_1280^5
+      const uint64_t w = UT[5 * k1 * rr];   // omega_256 = omega_1280^5
       x[2 * k1] = v2::p2_mul(x[2 * k1], w); x[2 * k1 + 1] = v2::p2_mul(x[2 * k1 + 1], w);
     }
     // ---- B2: DFT8 over e2 ----
@@ -814,7 +829,7 @@ __global__ void __launch_bounds__(640, 2) k1_cols5(DevPlan pl, const uint32_t* _
                    [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; });
     v2::dft8p<false, 1>(z);
 #pragma unroll
-    for (int k2 = 1; k2 < 8; ++k2) z[k2] = v2::p2_mul(z[k2], pl.UT1[20 * k2 * f3]);   // omega_64 = omega_1280^20
+    for (int k2 = 1; k2 < 8; ++k2) z[k2] = v2::p2_mul(z[k2], UT[20 * k2 * f3]);   // omega_64 = omega_1280^20
     z[0] = {gf::fold(z[0].a), gf::fold(z[0].b)};
     // ---- B3: DFT8 over e3 ----
     const uint32_t g2 = (t >> 2) & 7;   // reader (k0 | k1 | k2 | c): same decode, e3's place holds k2
@@ -833,15 +848,19 @@ __global__ void __launch_bounds__(640, 2) k1_cols5(DevPlan pl, const uint32_t* _
       if (j < 7) ca = gf::mul(ca, B);
     }
   }
+  PROBE_END(pl)
 }
 
 template <bool EXT>
-__global__ void __launch_bounds__(640, 2) k3_cols5(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits, uint64_t* __restrict__ cbuf,
+__global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits, uint64_t* __restrict__ cbuf,
                                                    uint32_t a, uint64_t scale, BackExt ext) {
   using v2::P2;
+  if (threadIdx.x >= kThreads) return;   // the two padding waves (kLaunchThreads)
   uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
-  const uint32_t t = threadIdx.x, T = v2::tile_of_block(pl, blockIdx.x, gridDim.x);
+  const uint32_t t = threadIdx.x, T = v2::tile_of_block(pl, PROBE_BLOCK(pl), PROBE_GRID(pl));
   v2::boost_if_late(pl.boost_tiles);
+  PROBE_BEGIN(pl)
+  const uint64_t* __restrict__ UT = stage_roots(pl, X);
   const uint32_t c = t & 3, g2 = (t >> 2) & 7, f1 = (t >> 5) & 3, f0 = t >> 7, f3 = g2;
   P2 x[8], z[8];
   {
@@ -860,7 +879,7 @@ __global__ void __launch_bounds__(640, 2) k3_cols5(DevPlan pl, const uint64_t* _
                  [&](int k) { return (((f0 * 4 + f1) * 8 + g2) * 8 + k) * 4 + c; },
                  [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; });
 #pragma unroll
-  for (int k2 = 1; k2 < 8; ++k2) { const uint32_t e = 20 * k2 * f3; z[k2] = v2::p2_mul(z[k2], pl.UT1[e ? kM1 - e : 0]); }
+  for (int k2 = 1; k2 < 8; ++k2) { const uint32_t e = 20 * k2 * f3; z[k2] = v2::p2_mul(z[k2], UT[e ? kM1 - e : 0]); }
   z[0] = {gf::fold(z[0].a), gf::fold(z[0].b)};
   v2::dft8p<true, 2>(z);   // k2 -> e2
   const uint32_t chi = t & 1, e3 = (t >> 1) & 7, e2 = (t >> 4) & 7, k0 = t >> 7;
@@ -873,7 +892,7 @@ __global__ void __launch_bounds__(640, 2) k3_cols5(DevPlan pl, const uint64_t* _
 #pragma unroll
     for (int k1 = 1; k1 < 4; ++k1) {
       const uint32_t e = 5 * k1 * rr;
-      const uint64_t w = pl.UT1[e ? kM1 - e : 0];
+      const uint64_t w = UT[e ? kM1 - e : 0];
       x[2 * k1] = v2::p2_mul(x[2 * k1], w); x[2 * k1 + 1] = v2::p2_mul(x[2 * k1 + 1], w);
     }
 #pragma unroll
@@ -892,7 +911,7 @@ __global__ void __launch_bounds__(640, 2) k3_cols5(DevPlan pl, const uint64_t* _
       const uint32_t r = (t + 512 * q) >> 2;
       P2 w5[5] = {y[5 * q], y[5 * q + 1], y[5 * q + 2], y[5 * q + 3], y[5 * q + 4]};
 #pragma unroll
-      for (int k0i = 1; k0i < 5; ++k0i) { const uint32_t e = r * k0i; w5[k0i] = v2::p2_mul(w5[k0i], pl.UT1[e ? kM1 - e : 0]); }
+      for (int k0i = 1; k0i < 5; ++k0i) { const uint32_t e = r * k0i; w5[k0i] = v2::p2_mul(w5[k0i], UT[e ? kM1 - e : 0]); }
       dft5p(w5, pl.W5c, true);
 #pragma unroll
       for (int d0 = 0; d0 < 5; ++d0) y[5 * q + d0] = w5[d0];
@@ -945,6 +964,7 @@ __global__ void __launch_bounds__(640, 2) k3_cols5(DevPlan pl, const uint64_t* _
       ext.cbuf2[size_t(T) * kM1 + i1] = carry;
     }
   }
+  PROBE_END(pl)
 }
 
 // chain starts omega_m^(i2 (k0 + 5 k1 + 20 k2)) TB[2 i2] and ratios omega_m^(160 i2) of the B3 thread map (and inverses with TBi)
@@ -1037,7 +1057,7 @@ hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
   const dim3 grid(pl.M2 / pl.C), block(512);
   if (v5_cols_shape(pl)) {
-    hipLaunchKernelGGL(v5::k1_cols5, grid, dim3(v5::kThreads), v5::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
+    hipLaunchKernelGGL(v5::k1_cols5, grid, dim3(v5::kLaunchThreads), v5::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
     return hipGetLastError();
   }
   switch (pl.M1) {
@@ -1050,7 +1070,7 @@ hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s) {
   const dim3 grid(pl.M2 / pl.C), block(512);
   if (v5_cols_shape(pl)) {
-    hipLaunchKernelGGL(v5::k3_cols5<false>, grid, dim3(v5::kThreads), v5::kLdsBytes, s, pl, W, digits, cbuf, a, scale, BackExt());
+    hipLaunchKernelGGL(v5::k3_cols5<false>, grid, dim3(v5::kLaunchThreads), v5::kLdsBytes, s, pl, W, digits, cbuf, a, scale, BackExt());
     return hipGetLastError();
   }
   switch (pl.M1) {
@@ -1063,7 +1083,7 @@ hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits
 hipError_t v2_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s) {
   const dim3 grid(pl.M2 / pl.C), block(512);
   if (v5_cols_shape(pl)) {
-    hipLaunchKernelGGL(v5::k3_cols5<true>, grid, dim3(v5::kThreads), v5::kLdsBytes, s, pl, W, digits, cbuf, a, uint64_t(1), x);
+    hipLaunchKernelGGL(v5::k3_cols5<true>, grid, dim3(v5::kLaunchThreads), v5::kLdsBytes, s, pl, W, digits, cbuf, a, uint64_t(1), x);
     return hipGetLastError();
   }
   switch (pl.M1) {
@@ -1083,6 +1103,16 @@ hipError_t v2_probe_launch(const DevPlan& pl, int kind, int grid_mult, int extra
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(v2::k2_rows4096<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((v2::k2_rows4096<0, 1>), dim3(pl.M1 * grid_mult), dim3(512), lds, s, pl, W, nullptr, W, 0u);
+    return hipGetLastError();
+  }
+  if (v5_cols_shape(pl)) {
+    const dim3 g5((pl.M2 / pl.C) * grid_mult), b5(v5::kLaunchThreads);
+    const size_t l5 = v5::kLdsBytes + size_t(extra_lds);
+    const void* f = kind == 0 ? reinterpret_cast<const void*>(v5::k1_cols5) : reinterpret_cast<const void*>(v5::k3_cols5<false>);
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(l5));
+    if (e != hipSuccess) return e;
+    if (kind == 0) hipLaunchKernelGGL(v5::k1_cols5, g5, b5, l5, s, pl, digits, cbuf, 0u, W);
+    else hipLaunchKernelGGL(v5::k3_cols5<false>, g5, b5, l5, s, pl, W, dout, cbuf, 1u, uint64_t(1), BackExt());
     return hipGetLastError();
   }
   if (pl.M1 != 1024) return hipErrorNotSupported;

@@ -21,8 +21,7 @@ from prmers_amd import Engine  # noqa: E402
 from prmers_amd.engine import load_library  # noqa: E402
 
 
-def probe(e, L, kind, mult, extra_lds, boost, iters, timeline=True):
-    base = 1024
+def probe(e, L, kind, mult, extra_lds, boost, iters, timeline=True, base=1024):
     grid = base * mult
     tl = np.zeros(grid * 8, dtype=np.uint64) if timeline else None
     ms = C.c_double(0)
@@ -78,7 +77,7 @@ def main():
     vp = C.c_void_p
     L.mi355_probe.restype = C.c_int
     L.mi355_probe.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_double), vp, C.c_size_t]
-    p = 136279841
+    p = int(sys.argv[3]) if len(sys.argv) > 3 else 136279841
     out = {}
     arrays = {}
     with Engine(p, 3) as e:
@@ -101,7 +100,8 @@ def main():
             cfgs = [(1, 0, 50, "x1"), (2, 0, 50, "x2"), (4, 0, 50, "x4")]
         for kind in (1, 0, 2):
             for (mult, lds, boost, label) in cfgs:
-                ms, tl = probe(e, L, kind, mult, lds, boost, 200)
+                base = (e.n // 2 // 4096) if kind == 1 else 1024        # rows: M1 (rows of 4096), columns: M2 / C tiles
+                ms, tl = probe(e, L, kind, mult, lds, boost, 200, base=base)
                 key = "%s_%s" % (names[kind], label)
                 out[key] = {"avg_us": round(ms * 1e3, 2)}
                 out[key].update(analyse(tl))
