@@ -100,6 +100,10 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     dp_.boost_tiles = from(pl_.tiles());
   }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));
+  if (pl_.split5) {
+    HIPCHK(configure_split(dp_));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&split_), reg_bytes_));
+  }
   {
     // kernel set: the register-resident radix-8 kernels where the shape is served, else the generic
     // set.  MI355_KERNELS=generic|v2rows|v2cols narrows it (A/B tests, debugging).
@@ -137,6 +141,7 @@ Engine::~Engine() {
   if (tables_) (void)hipFree(tables_);
   if (di_) (void)hipFree(di_);
   if (f0_) (void)hipFree(f0_);
+  if (split_) (void)hipFree(split_);
   if (canon_) (void)hipFree(canon_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -184,6 +189,11 @@ void Engine::carry_fix_now(size_t r) {
 }
 
 void Engine::run_front(size_t r) {
+  if (pl_.split5) {   // columns beyond LDS (n = 5 2^26): radix-5 stage through the second work buffer
+    normalize(r);
+    HIPCHK(launch_front_split(dp_, digits(r), split_, work(), stream_));
+    return;
+  }
   if (v2cols_) {
     HIPCHK(v2_launch_front(dp_, digits(r), pending_carry_[r] ? cbuf(r) : nullptr, pending_sub_[r], work(), stream_));
   } else if (pl_.C >= 2 && kind_[r] == kDigits && !pending_sub_[r]) {
@@ -202,6 +212,12 @@ void Engine::run_middle(const uint64_t* in, const uint64_t* y, uint64_t* out, in
 // work() -> digits(r) (+ run carries in cbuf(r)); the carry fix is deferred to the next front sweep
 // when that kernel can fold it in, otherwise applied right away
 void Engine::run_back(size_t r, uint32_t a) {
+  if (pl_.split5) {
+    HIPCHK(launch_back_split(dp_, work(), split_, digits(r), cbuf(r), a, stream_));
+    carry_fix_now(r);
+    pending_sub_[r] = 0;
+    return;
+  }
   if (v2cols_) {
     HIPCHK(v2_launch_back(dp_, work(), digits(r), cbuf(r), a, 1, stream_));
     pending_carry_[r] = 1;
@@ -444,6 +460,11 @@ void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
     HIPCHK(v2_launch_back(dp_, work(), digits(r), cbuf(r), a, 1, stream_));
     if (ev) { HIPCHK(hipEventRecord(ev[3], stream_)); HIPCHK(hipEventRecord(ev[4], stream_)); }
     pending_carry_[r] = 1;
+  } else if (pl_.split5) {
+    HIPCHK(launch_back_split(dp_, work(), split_, digits(r), cbuf(r), a, stream_));
+    if (ev) HIPCHK(hipEventRecord(ev[3], stream_));
+    carry_fix_now(r);
+    if (ev) HIPCHK(hipEventRecord(ev[4], stream_));
   } else {
     HIPCHK(launch_back(dp_, work(), digits(r), cbuf(r), a, stream_));
     if (ev) HIPCHK(hipEventRecord(ev[3], stream_));
@@ -568,7 +589,7 @@ void Engine::square_mul_copy(size_t src, size_t dst_copy, uint32_t a) {
   need_digits(src, "square_mul_copy"); check_reg(dst_copy);
   if (a == 0) throw std::runtime_error("square_mul_copy: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  if (dst_copy == src) { square_mul(src, a); copy(dst_copy, src); return; }
+  if (dst_copy == src || pl_.split5) { square_mul(src, a); copy(dst_copy, src); return; }
   run_front(src);
   run_middle(work(), nullptr, work(), 0, 0);
   back_ext(src, a, long(dst_copy), -1);
@@ -580,7 +601,7 @@ void Engine::mul_copy(size_t dst, size_t src, size_t dst_copy, uint32_t a) {
   if (dst == src || dst_copy == src) throw std::runtime_error("mul_copy: the multiplicand must differ from the outputs");
   if (a == 0) throw std::runtime_error("mul_copy: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  if (dst_copy == dst) { mul(dst, src, a); copy(dst_copy, dst); return; }
+  if (dst_copy == dst || pl_.split5) { mul(dst, src, a); copy(dst_copy, dst); return; }
   run_front(dst);
   run_middle(work(), image(src), work(), 1, 0);
   back_ext(dst, a, long(dst_copy), -1);
@@ -592,6 +613,10 @@ void Engine::mul_add(size_t dst, size_t mul_src, size_t add_src, uint32_t a) {
   if (dst == mul_src) throw std::runtime_error("mul_add: dst and mul_src must differ");
   if (a == 0) throw std::runtime_error("mul_add: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
+  if (pl_.split5) {   // the split sweeps have no fused variants: the base-class composition (engine.h:65-70)
+    if (add_src == dst) throw std::runtime_error("mul_add: add_src == dst needs the fused sweep, which this transform size does not have");
+    mul(dst, mul_src, a); add(dst, add_src); return;
+  }
   if (add_src != dst) digits_ready(add_src);
   else if (kind_[dst] != kDigits || pending_sub_[dst]) normalize(dst);
   run_front(dst);   // reads digits(dst) (+ pending carries) and leaves them in place
@@ -731,7 +756,8 @@ void Engine::probe(int kind, int grid_mult, int extra_lds, int boost_pct, size_t
     HIPCHK(hipGetDeviceProperties(&prop, device_));
     const size_t per_cu = extra_lds >= 20 * 1024 ? 1 : 2;
     const size_t slots = per_cu * size_t(prop.multiProcessorCount);
-    const uint32_t from = (boost_pct > 0 && grid > slots) ? uint32_t(grid - slots * size_t(boost_pct) / 100) : ~0u;
+    const int bp = boost_pct < 0 ? -boost_pct : boost_pct;
+    const uint32_t from = (bp > 0 && grid > slots) ? uint32_t(grid - slots * size_t(bp) / 100) : ~0u;
     d.boost_rows = d.boost_tiles = from;
   }
   uint64_t* dtl = nullptr;
@@ -753,6 +779,8 @@ void Engine::probe(int kind, int grid_mult, int extra_lds, int boost_pct, size_t
   HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
   if (tl) {
     d.probe = dtl;
+    // (boost_pct < 0: the instrumented launch follows a launch of ANOTHER kernel, as in a squaring, instead of a launch of itself)
+    if (boost_pct < 0) { if (kind == 1) HIPCHK(v2_launch_back(dp_, work(), dout, cbuf(0), 1, 1, stream_)); else run_middle(work(), nullptr, work(), 0, 0); }
     launch(d);
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipMemcpy(tl, dtl, grid * 64, hipMemcpyDeviceToHost));

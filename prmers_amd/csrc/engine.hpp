@@ -105,6 +105,7 @@ class Engine {
   uint64_t* cbuf_ = nullptr;                  // reg_count + 4 buffers of runs() carry words
   std::vector<uint64_t*> cb_, cb_spare_;      // cb_[r]: the buffer register r uses now
   void* tables_ = nullptr;
+  uint64_t* split_ = nullptr;   // second work buffer of the split column sweeps (plan.split5: n = 5 2^26)
   uint64_t* f0_ = nullptr;   // four-step chain starts / ratios of the register-resident column kernels
   uint32_t* di_ = nullptr;   // digit-info words of the register-resident column kernels (plan.hpp DI)
   std::vector<uint8_t> kind_;

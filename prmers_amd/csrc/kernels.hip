@@ -445,6 +445,116 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Columns too long for LDS: M1 = 5 L1 with 16 M1 bytes above a CU's 160 KiB -- n = 5 * 2^26, the largest entry of the reference's
+// schedule (include/marin/engine_gpu.h:1624; forward80_0 ... there).  The radix-5 stage of the column transform runs on its own through a
+// second work buffer U ([k0][i2][t]: 5 blocks x M2 columns x L1 pairs), one thread per (column, t) and C = 1; the power-of-two part of
+// every block stays LDS-resident (L1 pairs x Cb columns).  Four sweeps instead of two around the row kernel: correct first, this size
+// exists for exponents above 3.0e9.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_front_split_a(DevPlan pl, const uint32_t* __restrict__ digits, uint64_t* __restrict__ Uout) {
+  const size_t e = size_t(blockIdx.x) * 256 + threadIdx.x;
+  const uint32_t t = uint32_t(e & (pl.L1 - 1)), i2 = uint32_t(e >> pl.logL1), M1 = pl.M1;
+  if (i2 >= pl.M2) return;
+  const uint2* dg = reinterpret_cast<const uint2*>(digits) + size_t(i2) * M1;   // C = 1: tile i2 holds the column's M1 pairs
+  const uint32_t sb = pl.SB[2 * i2];
+  P2 x[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const uint32_t i1 = pl.L1 * r + t;
+    const uint2 d = dg[i1];
+    uint32_t w0, w1; bool wr0, wr1;
+    digit_info(pl, pl.SA[i1], sb, w0, wr0);
+    digit_info(pl, pl.SA[M1 + i1], sb, w1, wr1);
+    x[r] = {gf::mul_u32(gf::half(pl.TA[i1]), d.x << (wr0 ? 0 : 1)), gf::mul_u32(gf::half(pl.TA[M1 + i1]), d.y << (wr1 ? 0 : 1))};   // see k_front
+  }
+  dft5<false>(x, pl.W5c);
+#pragma unroll
+  for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[t * k]);
+  P2* U = reinterpret_cast<P2*>(Uout);
+#pragma unroll
+  for (int k0 = 0; k0 < 5; ++k0) U[(size_t(k0) * pl.M2 + i2) * pl.L1 + t] = x[k0];
+}
+// block k0, columns Cb T .. Cb T + Cb - 1: L1-point transforms in LDS, four-step twiddle, rows k0 L1 + p of the work buffer
+__global__ void __launch_bounds__(1024) k_front_split_b(DevPlan pl, const uint64_t* __restrict__ Uin, uint64_t* __restrict__ Wout, uint32_t logCb) {
+  P2* X = reinterpret_cast<P2*>(smem_raw);
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x, Cb = 1u << logCb, per = pl.M2 >> logCb;
+  const uint32_t k0 = blockIdx.x / per, T = blockIdx.x - k0 * per, tile = pl.L1 << logCb;
+  const P2* U = reinterpret_cast<const P2*>(Uin);
+  for (uint32_t e = tid; e < tile; e += nthr) {
+    const uint32_t c = e >> pl.logL1, pp = e & (pl.L1 - 1);   // reads run along t: contiguous
+    X[(pp << logCb) + c] = U[(size_t(k0) * pl.M2 + (T << logCb) + c) * pl.L1 + pp];
+  }
+  __syncthreads();
+  if (pl.logL1) lds_pow2_dft<false>(X, pl.L1, pl.logL1, 1, Cb, logCb, pl.UT1, pl.M1, pl.r5, pl.I4, tid, nthr);
+  P2* W = reinterpret_cast<P2*>(Wout);
+  for (uint32_t e = tid; e < tile; e += nthr) {
+    const uint32_t pp = e >> logCb, c = e & (Cb - 1), i2 = (T << logCb) + c, pos = k0 * pl.L1 + pp;
+    const uint64_t ex = uint64_t(i2) * freq1(pl, pos);
+    const uint64_t twb = gf::mul(tw_lookup(pl, ex), pl.TB[2 * i2]);
+    const P2 x = X[e];
+    W[size_t(pos) * pl.M2 + i2] = {gf::mul(x.a, twb), gf::mul(x.b, twb)};
+  }
+}
+__global__ void __launch_bounds__(1024) k_back_split_b(DevPlan pl, const uint64_t* __restrict__ Win, uint64_t* __restrict__ Uout, uint32_t logCb) {
+  P2* X = reinterpret_cast<P2*>(smem_raw);
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x, Cb = 1u << logCb, per = pl.M2 >> logCb;
+  const uint32_t k0 = blockIdx.x / per, T = blockIdx.x - k0 * per, tile = pl.L1 << logCb;
+  const P2* W = reinterpret_cast<const P2*>(Win);
+  for (uint32_t e = tid; e < tile; e += nthr) {
+    const uint32_t pp = e >> logCb, c = e & (Cb - 1), i2 = (T << logCb) + c, pos = k0 * pl.L1 + pp;
+    const uint64_t ex = uint64_t(i2) * freq1(pl, pos);
+    const uint64_t twb = gf::mul(tw_lookup(pl, ex ? pl.m - ex : 0), pl.TBi[2 * i2]);
+    const P2 x = W[size_t(pos) * pl.M2 + i2];
+    X[e] = {gf::mul(x.a, twb), gf::mul(x.b, twb)};
+  }
+  __syncthreads();
+  if (pl.logL1) lds_pow2_dft<true>(X, pl.L1, pl.logL1, 1, Cb, logCb, pl.UT1, pl.M1, pl.r5, pl.I4inv, tid, nthr);
+  P2* U = reinterpret_cast<P2*>(Uout);
+  for (uint32_t e = tid; e < tile; e += nthr) {
+    const uint32_t c = e >> pl.logL1, pp = e & (pl.L1 - 1);
+    U[(size_t(k0) * pl.M2 + (T << logCb) + c) * pl.L1 + pp] = X[(pp << logCb) + c];
+  }
+}
+// inverse radix-5 stage, unweighting, x a and the carry inside every pair (runs of two digits: the engine follows with k_carry_fix and
+// the local carry passes, as for every C = 1 plan)
+__global__ void __launch_bounds__(256) k_back_split_a(DevPlan pl, const uint64_t* __restrict__ Uin, uint32_t* __restrict__ digits, uint64_t* __restrict__ cbuf,
+                                                     uint32_t a) {
+  const size_t e = size_t(blockIdx.x) * 256 + threadIdx.x;
+  const uint32_t t = uint32_t(e & (pl.L1 - 1)), i2 = uint32_t(e >> pl.logL1), M1 = pl.M1;
+  if (i2 >= pl.M2) return;
+  const P2* U = reinterpret_cast<const P2*>(Uin);
+  P2 x[5];
+#pragma unroll
+  for (int k0 = 0; k0 < 5; ++k0) x[k0] = U[(size_t(k0) * pl.M2 + i2) * pl.L1 + t];
+#pragma unroll
+  for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[(t * k) ? M1 - t * k : 0]);
+  dft5<true>(x, pl.W5c);
+  uint2* dg = reinterpret_cast<uint2*>(digits) + size_t(i2) * M1;
+  const uint32_t sb = pl.SB[2 * i2];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const uint32_t i1 = pl.L1 * r + t;
+    const uint32_t sa[2] = {pl.SA[i1], pl.SA[M1 + i1]};
+    const uint64_t tai[2] = {pl.TAi[i1], pl.TAi[M1 + i1]};
+    uint64_t carry = 0;
+    uint32_t out[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      uint32_t width; bool wrap;
+      digit_info(pl, sa[b], sb, width, wrap);
+      const uint64_t u = gf::mul(b ? x[r].b : x[r].a, wrap ? gf::dbl(tai[b]) : tai[b]);
+      const uint64_t mask = (uint64_t(1) << width) - 1;
+      const uint64_t dlo = u & mask, chi = u >> width;      // adc_mul (marin.cl:194-201)
+      const uint64_t rr = dlo * a + carry;
+      out[b] = uint32_t(rr & mask);
+      carry = (rr >> width) + chi * a;
+    }
+    dg[i1] = make_uint2(out[0], out[1]);
+    cbuf[size_t(i2) * M1 + i1] = carry;
+  }
+}
+
 // One thread per run: a, b (+ their pending carry words) -> sum and / or difference, each written to up to two
 // registers, with the run's carry-out word left pending (kernels.hpp LinArgs).  The difference is a - b + 2 Mp
 // digit by digit (neg2_mp4, marin.cl:246-256), so nothing goes negative: digits are below 2^width + a small excess.
@@ -605,6 +715,31 @@ hipError_t launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digit
   const size_t tile = size_t(pl.M1) * pl.C;
   hipLaunchKernelGGL(k_back<true>, dim3(pl.M2 / pl.C), dim3(block_for_small(pl, tile)), tile * 16, s, pl, W, digits, cbuf, a, x);
   return hipGetLastError();
+}
+// the split column sweeps (M1 = 5 L1 beyond LDS): U is a second work buffer of 8 n bytes
+static uint32_t split_log_cb(const DevPlan& pl) { uint32_t l = 0; while ((size_t(pl.L1) << (l + 1)) * 16 <= size_t(128) * 1024 && (2u << l) <= pl.M2 && l < 2) ++l; return l; }
+hipError_t launch_front_split(const DevPlan& pl, const uint32_t* digits, uint64_t* U, uint64_t* W, hipStream_t s) {
+  const size_t threads = size_t(pl.M2) * pl.L1;
+  hipLaunchKernelGGL(k_front_split_a, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, s, pl, digits, U);
+  const uint32_t lcb = split_log_cb(pl);
+  const size_t tile = size_t(pl.L1) << lcb;
+  hipLaunchKernelGGL(k_front_split_b, dim3(5 * (pl.M2 >> lcb)), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, U, W, lcb);
+  return hipGetLastError();
+}
+hipError_t launch_back_split(const DevPlan& pl, const uint64_t* W, uint64_t* U, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s) {
+  const uint32_t lcb = split_log_cb(pl);
+  const size_t tile = size_t(pl.L1) << lcb;
+  hipLaunchKernelGGL(k_back_split_b, dim3(5 * (pl.M2 >> lcb)), dim3(block_for(tile / 4 ? tile / 4 : 1)), tile * 16, s, pl, W, U, lcb);
+  const size_t threads = size_t(pl.M2) * pl.L1;
+  hipLaunchKernelGGL(k_back_split_a, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, s, pl, U, digits, cbuf, a);
+  return hipGetLastError();
+}
+hipError_t configure_split(const DevPlan& pl) {
+  const size_t bytes = (size_t(pl.L1) << split_log_cb(pl)) * 16;
+  if (bytes <= 48 * 1024) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_split_b), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_split_b), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
 }
 hipError_t launch_linear(const DevPlan& pl, const LinArgs& la, hipStream_t s) {
   const size_t runs = size_t(pl.M1) * (pl.M2 / pl.C);

@@ -49,6 +49,10 @@ hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_
 hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
 hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t* cbuf, hipStream_t s);
+// columns of 5 L1 pairs that do not fit LDS (n = 5 * 2^26): the radix-5 stage through a second work buffer U (8 n bytes), C = 1
+hipError_t configure_split(const DevPlan& pl);
+hipError_t launch_front_split(const DevPlan& pl, const uint32_t* digits, uint64_t* U, uint64_t* W, hipStream_t s);
+hipError_t launch_back_split(const DevPlan& pl, const uint64_t* W, uint64_t* U, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
 hipError_t launch_addsub(const DevPlan& pl, uint32_t* dst, const uint32_t* src, uint64_t* cbuf, int negate, hipStream_t s);
 hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hipStream_t s);
 

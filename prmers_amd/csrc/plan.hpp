@@ -53,6 +53,7 @@ struct Plan {
   uint32_t M1 = 1, M2 = 1;  // m = M1 * M2, M2 = 2^logM2, M1 = r5 * L1, L1 = 2^logL1
   uint32_t L1 = 1, logL1 = 0, logM2 = 0;
   uint32_t C = 1;           // adjacent columns per front/back tile (runs of 2C digits)
+  bool split5 = false;      // columns of 5 L1 pairs beyond LDS: the radix-5 stage runs through memory (kernels.hip k_front_split_*), C = 1
   uint32_t q = 0, t = 0;    // p = q*n + t
   uint32_t twh = 0;         // omega_m^e = TWlo[e & (2^twh-1)] * TWhi[e >> twh]
   size_t lds_front = 0, lds_mid = 0;
@@ -91,7 +92,7 @@ struct Plan {
 
   std::string describe() const {
     char buf[160];
-    std::snprintf(buf, sizeof buf, "marin-hip:n=%zu:m1=%u:m2=%u:c=%u", n, M1, M2, C);
+    std::snprintf(buf, sizeof buf, "marin-hip:n=%zu:m1=%u:m2=%u:c=%u%s", n, M1, M2, C, split5 ? ":split5" : "");
     return buf;
   }
 };
@@ -108,6 +109,7 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   const int k = ilog2(pl.m / pl.r5);
 
   long want_m2 = -1, want_c = -1;
+  bool want_split = false;
   if (spec && *spec) {
     std::string s(spec);
     for (size_t i = 0; i < s.size();) {
@@ -116,6 +118,7 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
       const std::string tok = s.substr(i, e - i);
       if (tok.rfind("m2=", 0) == 0) want_m2 = std::atol(tok.c_str() + 3);
       else if (tok.rfind("c=", 0) == 0) want_c = std::atol(tok.c_str() + 2);
+      else if (tok == "split5") want_split = true;   // tests: the split column sweeps at a small 5 2^k size
       else if (!tok.empty() && tok != "marin-hip" && tok.rfind("n=", 0) != 0 && tok.rfind("m1=", 0) != 0)
         throw std::runtime_error("unknown plan token '" + tok + "'");
       i = e + 1;
@@ -136,14 +139,18 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   } else {
     // very large transforms: 8192-pair rows (128 KiB) so that M1 stays <= 2048
     while ((pl.m >> b) > 2048 && b < 13 && b < k) ++b;
+    if (pl.r5 == 5 && (pl.m >> b) > 10240 && b < k) b = std::min(13, k);   // n = 5 2^26: rows of 8192, columns of 5 x 4096 (split sweeps)
   }
   pl.logM2 = uint32_t(b);
   pl.M2 = 1u << b;
   pl.M1 = uint32_t(pl.m / pl.M2);
   pl.L1 = pl.M1 / pl.r5;
   pl.logL1 = uint32_t(ilog2(pl.L1));
-  // columns live in LDS on the generic kernel set: M1 x C pairs of 16 bytes within the 160 KiB of a CU
-  if (size_t(pl.M1) * 16 > 160 * 1024) throw std::runtime_error("transform size not supported yet (n > 5*2^25: columns of more than 10240 pairs)");
+  // columns live in LDS on the generic kernel set: M1 x C pairs of 16 bytes within the 160 KiB of a CU; beyond that (n = 5 2^26:
+  // 5 x 4096 pairs) the radix-5 stage goes through memory and only the L1 = M1 / 5 part needs LDS
+  if (want_split && pl.r5 != 5) throw std::runtime_error("split5 needs a 5 * 2^k transform");
+  pl.split5 = want_split || size_t(pl.M1) * 16 > 160 * 1024;
+  if (pl.split5 && (pl.r5 != 5 || size_t(pl.L1) * 16 > 128 * 1024)) throw std::runtime_error("transform size not supported (columns beyond the split sweeps)");
 
   // tile: up to 4096 pairs (64 KiB), runs of at most 16 pairs (256 B of the work buffer);
   // grow to 8192 pairs (128 KiB) when that is what C >= 4 needs
@@ -155,12 +162,13 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   // runs of two digits cannot absorb the run carries of a large transform (they leave log2(n) - 2 excess bits on a digit):
   // take C = 2 wherever the tile still fits the 160 KiB of LDS; beyond that the engine adds a local carry pass
   if (C == 1 && pl.M2 >= 2 && size_t(pl.M1) * 2 * 16 <= 160 * 1024 && pl.n >= (size_t(1) << 19)) C = 2;
-  if (want_c > 0) {
+  if (pl.split5) C = 1;
+  if (want_c > 0 && !pl.split5) {
     C = uint32_t(want_c);
     if ((C & (C - 1)) != 0 || C > pl.M2 || size_t(pl.M1) * C > 10240) throw std::runtime_error("bad c in plan spec");
   }
   pl.C = C;
-  pl.lds_front = size_t(pl.M1) * pl.C * 16;
+  pl.lds_front = pl.split5 ? 0 : size_t(pl.M1) * pl.C * 16;
   pl.lds_mid = size_t(pl.M2) * 16;
   pl.q = uint32_t(p / pl.n);
   pl.t = uint32_t(p % pl.n);

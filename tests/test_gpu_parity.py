@@ -36,6 +36,10 @@ SMALL_CASES = [
     (400063, "m2=8,c=4"), (800283, "m2=16,c=4"), (1600589, "m2=32,c=4"),
     # rows of 8192 (two 4096-point halves under one radix-2 level, 1024 threads)
     (300007, "m2=8192"), (600011, "m2=8192"), (1200007, "m2=8192,c=2"),
+    # the split column sweeps of n = 5 * 2^26 (radix-5 stage through memory, power-of-two part in LDS) forced at small 5 * 2^k sizes:
+    # L1 = 4 .. 2048, generic rows and the register-resident rows of 4096 / 8192
+    (1001, "m2=2,split5"), (3585, "m2=4,split5"), (13825, "m2=8,split5"), (53331, "m2=16,split5"), (400063, "m2=8,split5"),
+    (800283, "m2=4096,split5"), (1600589, "m2=8192,split5"), (3200123, "m2=8,split5"), (3200123, "m2=4096,split5"),
 ]
 
 
@@ -335,11 +339,37 @@ def test_largest_supported_transforms(p, n):
         assert e.res64(0) == o.res64(0)
 
 
-def test_unsupported_transform_size_is_refused():
-    """n = 5*2^26 (the reference's largest schedule entry, engine_gpu.h:1624) needs columns of 20480 pairs, more than a CU's
-    LDS holds: creation fails loudly."""
-    with pytest.raises(Exception, match="not supported"):
-        Engine(4000000007, 2)
+def test_largest_transform_size_of_the_reference_schedule():
+    """n = 5 * 2^26 (include/marin/engine_gpu.h:1624), the last of the 46 sizes: columns of 20480 = 5 x 4096 pairs do not fit a CU's LDS, so
+    the radix-5 stage of the column transform runs through a second work buffer (kernels.hip k_front_split_* / k_back_split_*).  One seeded
+    squaring + LL step against the oracle's digit vector, then 3^(2^34) against the libgmp pins (tests/golden/largest_p_pins.json)."""
+    import hashlib
+    from prmers_amd import resolve_plan
+    p = 4000000007
+    assert resolve_plan(p) == "marin-hip:n=335544320:m1=20480:m2=8192:c=1:split5"
+    o = orc.Oracle(p, 1)
+    assert o.n == 5 << 26
+    rng = np.random.default_rng(p)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 2) as e:
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        e.square_mul(0, 3); o.square_mul(0, 3)
+        e.sub(0, 2); o.sub(0, 2)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert e.res64(0) == o.res64(0)
+        del o
+        e.copy(1, 0)
+        assert e.is_equal(0, 1)
+        pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "largest_p_pins.json")))["pins"][str(p)]
+        e.set(0, 3)
+        it = 0
+        for pin in pins:
+            while it < pin["iteration"]:
+                e.square_mul(0); it += 1
+            wds = e.words(0)
+            assert "%016X" % (int(wds[0]) | (int(wds[1]) << 32)) == pin["res64"], (p, it)
+            assert hashlib.sha256(wds.astype("<u4").tobytes()).hexdigest() == pin["sha256_words"], (p, it)
 
 
 @pytest.mark.parametrize("p,n,plan", [(800000011, 1 << 26, "m1=4096:m2=8192:c=2"), (1300000003, 5 << 24, "m1=5120:m2=8192:c=2"),

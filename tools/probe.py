@@ -97,7 +97,9 @@ def main():
         cfgs = [(1, 0, 50, "x1"), (1, 0, 0, "x1_noboost"), (2, 0, 50, "x2"), (4, 0, 50, "x4"), (4, 0, 0, "x4_noboost"),
                 (1, 24 * 1024, 0, "x1_one_group_per_cu"), (2, 24 * 1024, 0, "x2_one_group_per_cu")]
         if quick:
-            cfgs = [(1, 0, 50, "x1"), (2, 0, 50, "x2"), (4, 0, 50, "x4")]
+            cfgs = [(1, 0, 50, "x1"), (1, 0, -50, "x1_after_another_kernel"), (2, 0, 50, "x2"), (4, 0, 50, "x4")]
+        if len(sys.argv) > 4:   # extra padding LDS values to try (bytes)
+            cfgs = [(1, int(x), 50, "x1_lds+%s" % x) for x in sys.argv[4].split(",")] + [(1, int(x), -50, "x1_after_another_kernel_lds+%s" % x) for x in sys.argv[4].split(",")]
         for kind in (1, 0, 2):
             for (mult, lds, boost, label) in cfgs:
                 base = (e.n // 2 // 4096) if kind == 1 else 1024        # rows: M1 (rows of 4096), columns: M2 / C tiles
