@@ -157,13 +157,25 @@ __global__ void __launch_bounds__(256) k_apply(CanonGeom g, const T* __restrict_
 // For plans whose runs are only two digits long (C = 1): the weak carry of a back sweep then leaves up to log2(n) - 2
 // excess bits on a run's second digit, too much for the next squaring once n >= 2^19; one pass brings it down to
 // log2(n) - 2 - w bits (the reference spreads a work-group's last carry over four digits, adc4 marin.cl:203-212).
+// One thread per PAIR in memory order (tile T, row i1, column c): its two digits are one 8-byte word, the digit before the pair is the
+// odd digit of the pair one column to the left -- the previous pair of the run, or the last pair of the same row in tile T - 1 -- so every
+// access of a wavefront runs along i1 and is coalesced (the round-2 form walked the digits in natural order: 4-byte gathers M1 pairs
+// apart, 4.3 ms of a 12.1 ms squaring at n = 5 2^25).
 __global__ void __launch_bounds__(256) k_relax(CanonGeom g, const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= g.n) return;
-  const uint32_t jp = j ? j - 1 : g.n - 1;
-  const uint64_t o0 = ceil_pj_n(g, jp), o1 = ceil_pj_n(g, uint64_t(jp) + 1), o2 = ceil_pj_n(g, uint64_t(j) + 1);
-  const uint32_t wp = uint32_t(o1 - o0), w = uint32_t(o2 - (j ? o1 : 0));
-  out[pos_of(g, j)] = (in[pos_of(g, j)] & ((1u << w) - 1u)) + (in[pos_of(g, jp)] >> wp);
+  const size_t e = size_t(blockIdx.x) * 256 + threadIdx.x;   // pair index in memory: (T M1 + i1) C + c
+  if (e >= g.n / 2) return;
+  const uint32_t c = uint32_t(e % g.C), i1 = uint32_t((e / g.C) % g.M1), T = uint32_t(e / (size_t(g.C) * g.M1));
+  const uint32_t i2 = T * g.C + c;
+  const uint64_t j = 2 * (uint64_t(i1) * g.M2 + i2);        // natural index of the pair's even digit
+  // the pair to the left in digit order: column i2 - 1 of the same row, or the last column of the row above (cyclic)
+  const uint32_t pi1 = i2 ? i1 : (i1 ? i1 - 1 : g.M1 - 1), pi2 = i2 ? i2 - 1 : g.M2 - 1;
+  const size_t pe = (size_t(pi2 / g.C) * g.M1 + pi1) * g.C + (pi2 % g.C);
+  const uint64_t jp = j ? j - 1 : uint64_t(g.n) - 1;
+  const uint64_t o0 = ceil_pj_n(g, jp), o1 = j ? ceil_pj_n(g, j) : 0, o2 = ceil_pj_n(g, j + 1), o3 = ceil_pj_n(g, j + 2);
+  const uint32_t wp = uint32_t((j ? o1 : uint64_t(g.p)) - o0), w0 = uint32_t(o2 - o1), w1 = uint32_t(o3 - o2);
+  const uint2 d = reinterpret_cast<const uint2*>(in)[e];
+  const uint32_t prev_odd = in[2 * pe + 1];
+  reinterpret_cast<uint2*>(out)[e] = make_uint2((d.x & ((1u << w0) - 1u)) + (prev_odd >> wp), (d.y & ((1u << w1) - 1u)) + (d.x >> w0));
 }
 
 // natural order -> tile-major (set_digits / set_words without the host-side re-tiling)
@@ -243,7 +255,7 @@ uint32_t* canon_flags(const DevPlan& pl, uint32_t* scratch) {
   return scratch + 2 * size_t(pl.n) + 2 * nb;
 }
 hipError_t canon_relax(const DevPlan& pl, uint32_t p, const uint32_t* in, uint32_t* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_relax, dim3((pl.n + 255) / 256), dim3(256), 0, s, geom_of(pl, p), in, out);
+  hipLaunchKernelGGL(k_relax, dim3(uint32_t((size_t(pl.n) / 2 + 255) / 256)), dim3(256), 0, s, geom_of(pl, p), in, out);
   return hipGetLastError();
 }
 hipError_t canon_scatter(const DevPlan& pl, uint32_t p, const uint32_t* nat, uint32_t* digits, hipStream_t s) {
