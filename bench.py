@@ -94,12 +94,20 @@ def bench_crt(args):
     ms = 1e3 * elapsed / args.steps
     dom = max(kern, key=kern.get)
     bytes_iter = eng.algorithmic_bytes()
+    traffic = None
+    try:   # HBM bytes per squaring from the committed PMC passes of this command (tools/profile.sh, tools/make_traffic_json.py)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_crt_latest.json")))
+        if tj.get("plan") == eng.describe():
+            traffic = tj.get("per_squaring")
+    except Exception:
+        traffic = None
     out = {"metric": "squaring throughput at p=%d over GF(M61^2) x GF(M31^2), PFA radix-%d axis" % (p, args.odd), "value": round(args.steps / elapsed, 3),
            "unit": "iter/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u64 + u32 (GF(M61^2) x GF(M31^2))", "data": "synthetic",
            "config": {"workload": "square_mul x<-x^2 mod 2^p-1, p=%d, n=%d words (odd radix %d)" % (p, n, args.odd), "plan": eng.describe()},
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(bytes_iter / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(bytes_iter / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(bytes_iter / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_source": "profiles/traffic_crt_latest.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                         "algorithmic_bytes_per_iteration": bytes_iter, "stage_ms": {k: round(v, 5) for k, v in kern.items()},
                         "note": "whole iteration (stages are several launches each); first kernel set, see DESIGN.md section N1"}}
     print(json.dumps(out))
