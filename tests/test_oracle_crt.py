@@ -92,9 +92,10 @@ def test_reference_held_m11213_residues_pin_this_oracle(odd):
     assert prp.format_res64(w) == GOLD["m11213_final"]["res64"] and prp.format_res2048(w) == "0" * 511 + "1"
 
 
-@pytest.mark.parametrize("odd", [3, 9])
+@pytest.mark.parametrize("odd", [9])
 def test_reference_held_m100003_residue_pins_this_oracle(odd):
-    """unit_tests.sh:140-141: res64 and res2048 of the type-1 PRP residue of the composite M100003"""
+    """unit_tests.sh:140-141: res64 and res2048 of the type-1 PRP residue of the composite M100003 (radix 9 here; the GPU suite runs the
+    vector through the HIP engine at radix 3 and 9)"""
     import prmers_amd.prp as prp
     p = 100003
     o = orc_crt.OracleCrt(p, odd)
