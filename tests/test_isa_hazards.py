@@ -37,3 +37,19 @@ def test_shipped_kernels_have_no_unpadded_sgpr_hazard(src):
     with tempfile.TemporaryDirectory() as td:
         out = subprocess.run([sys.executable, CHECK, _isa(os.path.join(ROOT, src), td)], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout[-2000:]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_committed_valu_model_matches_the_shipped_kernels(tmp_path):
+    """profiles/valu_model_latest.json (read by bench.py for roofline.valu) must describe the kernels in the tree: the ISA walk of
+    tools/valu_model.py is repeated here and compared with the committed figures (instructions and issue cycles per wave, 1 %)."""
+    import json
+    out = tmp_path / "model.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "valu_model.py"), "--out", str(out)], stdout=subprocess.DEVNULL)
+    fresh = json.load(open(out))
+    committed = json.load(open(os.path.join(ROOT, "profiles", "valu_model_latest.json")))
+    assert fresh["plan"] == committed["plan"]
+    for slot, k in fresh["kernels"].items():
+        c = committed["kernels"][slot]
+        assert abs(k["valu_insts_per_wave"] - c["valu_insts_per_wave"]) <= 0.01 * c["valu_insts_per_wave"], (slot, k, c)
+        assert abs(k["issue_cycles_per_wave"] - c["issue_cycles_per_wave"]) <= 0.01 * c["issue_cycles_per_wave"], (slot, k, c)
