@@ -72,6 +72,10 @@ MI355_ENGINE_API int mi355_engine_mul_add(mi355_engine_handle handle, size_t dst
 MI355_ENGINE_API int mi355_engine_square_mul_copy(mi355_engine_handle handle, size_t src, size_t dst_copy, uint32_t factor);
 /* dst = dst * src * factor, dst_copy = dst (engine.h:91) */
 MI355_ENGINE_API int mi355_engine_mul_copy(mi355_engine_handle handle, size_t dst, size_t src, size_t dst_copy, uint32_t factor);
+/* count x { reg = reg^2 * factor; reg -= sub } -- the run of squarings a PRP (sub = 0) or Lucas-Lehmer (sub = 2) loop issues between two
+   checks (src/modes/RunPrpOrLlMarin.cpp:338-409: one square_mul, and for LL one sub, per iteration).  Same result as the loop of
+   mi355_engine_square_mul / mi355_engine_sub_u32 calls; transforms of at most 2^20 words run it as ONE cooperative launch. */
+MI355_ENGINE_API int mi355_engine_square_mul_n(mi355_engine_handle handle, size_t reg, uint32_t factor, size_t count, uint32_t sub);
 
 /* ---- rest of the engine surface the Marin callers use ---- */
 /* engine::get / engine::set(Reg, uint64*) (engine.h:24-25): n digits, value | width << 32, strongly

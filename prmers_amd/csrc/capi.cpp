@@ -151,6 +151,12 @@ int mi355_engine_addsub_copy(mi355_engine_handle h, size_t s1, size_t d1, size_t
 }
 int mi355_engine_mul_add(mi355_engine_handle h, size_t dst, size_t ms, size_t as, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->mul_add(dst, ms, as, f); else eng(h)->mul_add(dst, ms, as, f); }); }
 int mi355_engine_square_mul_copy(mi355_engine_handle h, size_t src, size_t cp, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->square_mul_copy(src, cp, f); else eng(h)->square_mul_copy(src, cp, f); }); }
+int mi355_engine_square_mul_n(mi355_engine_handle h, size_t r, uint32_t f, size_t count, uint32_t sub) {
+  return guarded([&] {
+    if (crt(h)) { for (size_t i = 0; i < count; ++i) { crt(h)->square_mul(r, f); if (sub) crt(h)->sub_u32(r, sub); } }
+    else eng(h)->square_mul_n(r, f, count, sub);
+  });
+}
 int mi355_engine_mul_copy(mi355_engine_handle h, size_t dst, size_t src, size_t cp, uint32_t f) { return guarded([&] { if (crt(h)) crt(h)->mul_copy(dst, src, cp, f); else eng(h)->mul_copy(dst, src, cp, f); }); }
 
 int mi355_engine_get_digits(mi355_engine_handle h, size_t src, uint64_t* d, size_t count) {
@@ -195,7 +201,7 @@ const char* mi355_engine_kernel_name(mi355_engine_handle h, size_t k) {
 }
 int mi355_engine_describe(mi355_engine_handle h, char* output, size_t output_size) {
   return guarded([&] {
-    const std::string s = crt(h) ? crt(h)->describe() : eng(h)->plan().describe();
+    const std::string s = crt(h) ? crt(h)->describe() : eng(h)->describe();
     if (!output || s.size() + 1 > output_size) throw std::runtime_error("describe: output buffer too small");
     std::memcpy(output, s.c_str(), s.size() + 1);
   });

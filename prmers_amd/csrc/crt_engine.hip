@@ -38,6 +38,7 @@ struct Grid {
   uint64_t r61[9], r61i[9], s61, c3_61;               // odd-root powers r^e, their inverses, 1 / (odd h), (w3 - w3^2) / 2
   uint32_t r31[9], r31i[9], s31, c3_31;
   uint32_t mm, pm, lpm61, lpm31;                      // m mod odd; p m mod n and its images l61 (p m) mod 61, l31 (p m) mod 31
+  uint32_t tune;                                      // MI355_CRT_TUNE (A/B runs): bit 0 plain tile order in the column kernels
 };
 
 template <class F>
@@ -480,6 +481,7 @@ CrtEngine::CrtEngine(uint32_t p, size_t reg_count, uint32_t odd, size_t n_forced
       gr.pm = uint32_t((uint64_t(p) * gr.m) % n);
       gr.lpm61 = uint32_t(uint64_t(im.g.l61) * (gr.pm % 61) % 61); gr.lpm31 = uint32_t(uint64_t(im.g.l31) * (gr.pm % 31) % 31);
     }
+    { const char* tn = std::getenv("MI355_CRT_TUNE"); gr.tune = tn ? uint32_t(std::atoi(tn)) : 0u; }
     gr.s61 = pow61((uint64_t(odd) * gr.h) % M61, M61 - 2); gr.s31 = pow31(uint32_t((uint64_t(odd) * gr.h) % M31), M31 - 2);
 
     im.device = device;

@@ -246,13 +246,21 @@ __device__ __forceinline__ Planes planes_of(unsigned char* smem) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_crt[];
 
+// Work-group b runs on XCD b mod 8 (round-robin dispatch), each XCD with its own L2.  Adjacent column tiles share 128-byte lines on the
+// strided side of the four-step (CA slots of 16 or 8 bytes per row of the view), so XCD x takes the x-th contiguous eighth of the tiles:
+// the groups b, b + 8, b + 16, ... of one XCD are neighbours in memory and in time, and both halves (all quarters) of a line meet in one L2.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t groups, uint32_t tune) {   // MI355_CRT_TUNE bit 0: plain order (A/B runs)
+  return ((groups & 7u) || (tune & 1u)) ? b : (b & 7u) * (groups >> 3) + (b >> 3);
+}
+
 // ---- columns ----
 template <bool INV>
 __global__ void __launch_bounds__(256) k_cols_fast(Grid gr, FastTables T, F61::C* __restrict__ Z61, F31::C* __restrict__ Z31) {
   const Planes P = planes_of(smem_crt);
   const uint32_t tid = threadIdx.x, logL = gr.logH1, H2 = 1u << gr.logH2;
   const uint32_t CA = kFastSlots >> logL, per_row = H2 / CA;
-  const uint32_t row = blockIdx.x / per_row, col0 = (blockIdx.x - row * per_row) * CA;
+  const uint32_t bid = xcd_tile(blockIdx.x, gridDim.x, gr.tune);
+  const uint32_t row = bid / per_row, col0 = (bid - row * per_row) * CA;
   F61::C* z61 = Z61 + size_t(row) * gr.h; F31::C* z31 = Z31 + size_t(row) * gr.h;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -328,7 +336,8 @@ __global__ void __launch_bounds__(SLOTS / 8) k_cols_one(Grid gr, const typename 
   P.re = reinterpret_cast<uint64_t*>(smem_crt); P.im = P.re + PLANE; P.c3 = reinterpret_cast<uint2*>(smem_crt);   // one field: planes may overlap in name only
   const uint32_t tid = threadIdx.x, logL = gr.logH1, H2 = 1u << gr.logH2;
   const uint32_t CA = SLOTS >> logL, per_row = H2 / CA;
-  const uint32_t row = blockIdx.x / per_row, col0 = (blockIdx.x - row * per_row) * CA;
+  const uint32_t bid = xcd_tile(blockIdx.x, gridDim.x, gr.tune);
+  const uint32_t row = bid / per_row, col0 = (bid - row * per_row) * CA;
   C* z = Z + size_t(row) * gr.h;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {

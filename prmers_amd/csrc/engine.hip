@@ -121,6 +121,21 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     }
   }
 
+  {
+    // transforms whose tiles are all resident at once: one cooperative launch per run of squarings instead of three launches per
+    // squaring (kernels.hip k_coop).  Opt-in (MI355_COOP=1): measured slower on MI355X -- 0.044 ms per squaring at C2 inside one launch
+    // against 0.031 ms for three launches; a grid barrier costs what a kernel boundary costs (2.9 vs 2.8 us, tools/microbench_gridsync.hip),
+    // the hand-over data has to bypass the XCD's L2, and a cooperative launch itself takes 21.6 us.
+    const char* co = std::getenv("MI355_COOP");
+    if (!v2rows_ && !v2cols_ && !pl_.split5 && co && co[0] == '1') coop_groups_ = coop_groups(dp_, device_);
+    if (coop_groups_) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&coop_flags_), (size_t(coop_groups_) + 64) * 4));
+      HIPCHK(hipMemsetAsync(coop_flags_, 0, (size_t(coop_groups_) + 64) * 4, stream_));
+      const char* cb = std::getenv("MI355_COOP_BATCH");
+      if (cb && std::atoi(cb) > 1) coop_batch_ = size_t(std::atoi(cb));
+    }
+  }
+
   // digit widths in natural order (ibdwt.h:127-132), s_j = p*j mod n kept incrementally
   width_.resize(pl_.n);
   uint64_t s = 0;
@@ -143,6 +158,7 @@ Engine::~Engine() {
   if (f0_) (void)hipFree(f0_);
   if (split_) (void)hipFree(split_);
   if (canon_) (void)hipFree(canon_);
+  if (coop_flags_) (void)hipFree(coop_flags_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -157,6 +173,32 @@ void Engine::need_digits(size_t r, const char* op) const {
 void Engine::sync() {
   HIPCHK(hipSetDevice(device_));
   HIPCHK(hipStreamSynchronize(stream_));
+  coop_check();
+}
+
+// The grid barrier of k_coop gives up after 0.2 s and raises the error word; the results of that launch are garbage.
+void Engine::coop_check() {
+  if (coop_failed_) throw std::runtime_error("cooperative squaring kernel: a grid barrier timed out earlier; the engine's registers are not valid");
+  if (!coop_used_) return;
+  uint32_t err = 0;
+  HIPCHK(hipMemcpyAsync(&err, coop_flags_ + coop_groups_, 4, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  coop_used_ = false;
+  if (err) { coop_failed_ = true; throw std::runtime_error("cooperative squaring kernel: grid barrier timed out (work-groups not co-resident?)"); }
+}
+
+void Engine::coop_launch(size_t r, uint32_t a, size_t count, uint32_t sub_next) {
+  if (coop_failed_) coop_check();
+  while (count) {
+    const uint32_t c = uint32_t(std::min<size_t>(count, 1u << 20));
+    HIPCHK(launch_coop(dp_, coop_groups_, digits(r), cbuf(r), pending_carry_[r] != 0, work(), a, pending_sub_[r], sub_next, c, coop_flags_,
+                       coop_flags_ + coop_groups_, coop_epoch_, stream_));
+    coop_epoch_ += 3 * c - 1;
+    pending_carry_[r] = 1;
+    pending_sub_[r] = sub_next;
+    coop_used_ = true;
+    count -= c;
+  }
 }
 
 void Engine::normalize(size_t r) {
@@ -452,6 +494,11 @@ void Engine::copy(size_t dst, size_t src) {
 
 void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
   if (ev) HIPCHK(hipEventRecord(ev[0], stream_));
+  if (coop_groups_ && pending_sub_[r] < (1u << 30)) {   // one launch: the whole squaring sits in slot 0
+    coop_launch(r, a, 1, 0);
+    if (ev) for (int k = 1; k <= 4; ++k) HIPCHK(hipEventRecord(ev[k], stream_));
+    return;
+  }
   run_front(r);
   if (ev) HIPCHK(hipEventRecord(ev[1], stream_));
   run_middle(work(), nullptr, work(), 0, 0);
@@ -480,6 +527,15 @@ void Engine::square_mul(size_t r, uint32_t a) {
   if (a == 0) throw std::runtime_error("square_mul: factor must be >= 1");
   HIPCHK(hipSetDevice(device_));
   square_chain(r, a, nullptr);
+}
+
+void Engine::square_mul_n(size_t r, uint32_t a, size_t count, uint32_t sub) {
+  need_digits(r, "square_mul_n");
+  if (a == 0) throw std::runtime_error("square_mul_n: factor must be >= 1");
+  if (count == 0) return;
+  HIPCHK(hipSetDevice(device_));
+  if (coop_groups_ && pending_sub_[r] < (1u << 30) && sub < (1u << 30)) { coop_launch(r, a, count, sub); return; }
+  for (size_t i = 0; i < count; ++i) { square_chain(r, a, nullptr); if (sub) sub_u32(r, sub); }
 }
 
 void Engine::prepare(size_t dst, size_t src) {
@@ -628,7 +684,7 @@ void Engine::sub_u32(size_t r, uint32_t v) {
   need_digits(r, "sub");
   if (v == 0) return;
   HIPCHK(hipSetDevice(device_));
-  if (v2cols_ && uint64_t(pending_sub_[r]) + v < (1u << 30)) { pending_sub_[r] += v; return; }  // folded into the next front / middle sweep
+  if ((v2cols_ || coop_groups_) && uint64_t(pending_sub_[r]) + v < (1u << 30)) { pending_sub_[r] += v; return; }  // folded into the next front / middle sweep
   // the small subtraction only touches the digit vector (cyclic borrow), so run carries that are still pending
   // for the next front sweep can stay pending: value = digits + carries - v either way
   if (!(kind_[r] == kDigits && pl_.C >= 2 && !pending_sub_[r])) normalize(r);
@@ -690,9 +746,13 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipEventRecord(e0, stream_));
-  for (size_t i = 0; i < iters; ++i) {
-    square_chain(r, a, nullptr);
-    if (sub) sub_u32(r, sub);
+  if (coop_groups_ && coop_batch_ > 1) {   // MI355_COOP_BATCH squarings per launch (what a PRP / LL loop between two checks does)
+    for (size_t done = 0; done < iters;) { const size_t c = std::min(coop_batch_, iters - done); square_mul_n(r, a, c, sub); done += c; }
+  } else {
+    for (size_t i = 0; i < iters; ++i) {
+      square_chain(r, a, nullptr);
+      if (sub) sub_u32(r, sub);
+    }
   }
   HIPCHK(hipEventRecord(e1, stream_));
   HIPCHK(hipEventSynchronize(e1));
@@ -735,8 +795,9 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
     for (auto& x : ev) HIPCHK(hipEventDestroy(x));
     // which of the five slots hold a kernel on this path
     const bool fix_now = !v2cols_ && pl_.C < 2;                        // k_carry_fix right after the back sweep
-    const bool sub_kernel = sub != 0 && !(v2cols_ && sub < (1u << 30));          // k_sub_small (else folded into the next front sweep)
-    const bool launched[5] = {true, true, true, fix_now, sub_kernel};
+    const bool coop = coop_groups_ != 0;                               // one launch (slot 0) for the whole squaring
+    const bool sub_kernel = sub != 0 && !((v2cols_ || coop) && sub < (1u << 30));          // k_sub_small (else folded into the next front sweep)
+    const bool launched[5] = {true, !coop, !coop, fix_now && !coop, sub_kernel};
     for (size_t k = 0; k < 5 && k < kcount; ++k) kernel_ms[k] = launched[k] ? std::max(0.0, kernel_ms[k] - overhead) : -1.0;
     if (kcount > 5) kernel_ms[5] = overhead;
   }

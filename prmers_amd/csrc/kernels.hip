@@ -17,6 +17,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gf.hpp"
 #include "kernels.hpp"
 
@@ -28,6 +30,36 @@ __device__ __forceinline__ P2 p2_add(P2 x, P2 y) { return {gf::add(x.a, y.a), gf
 __device__ __forceinline__ P2 p2_sub(P2 x, P2 y) { return {gf::sub(x.a, y.a), gf::sub(x.b, y.b)}; }
 __device__ __forceinline__ P2 p2_mul(P2 x, uint64_t w) { return {gf::mul(x.a, w), gf::mul(x.b, w)}; }
 __device__ __forceinline__ P2 p2_shift48(P2 x) { return {gf::mul_pow2(x.a, 48), gf::mul_pow2(x.b, 48)}; }
+
+// Accesses to the data the sweeps hand to each other (work buffer, digits, run carries).  COH = false: plain loads and stores (the
+// three-launch chain: a kernel boundary makes them visible).  COH = true (k_coop: producer and consumer run in the same launch on
+// different XCDs, whose L2s are not coherent with each other): agent-scope relaxed atomics, i.e. loads and stores with the sc1 bit that
+// go to the memory side instead of the XCD's L2 -- the grid barrier then needs no L2 write-back / invalidate, which costs ~18 us each
+// (measured: 0.073 ms per squaring at C2 with agent-scope fences against 0.032 for three launches).
+template <bool COH> __device__ __forceinline__ uint64_t ld64(const uint64_t* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool COH> __device__ __forceinline__ void st64(uint64_t* p, uint64_t v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH> __device__ __forceinline__ P2 ldp2(const P2* p) {
+  if (COH) return {ld64<true>(&p->a), ld64<true>(&p->b)};
+  return *p;
+}
+template <bool COH> __device__ __forceinline__ void stp2(P2* p, P2 v) {
+  if (COH) { st64<true>(&p->a, v.a); st64<true>(&p->b, v.b); }
+  else *p = v;
+}
+template <bool COH> __device__ __forceinline__ uint2 ldu2(const uint2* p) {
+  if (COH) { const uint64_t v = ld64<true>(reinterpret_cast<const uint64_t*>(p)); return make_uint2(uint32_t(v), uint32_t(v >> 32)); }
+  return *p;
+}
+template <bool COH> __device__ __forceinline__ void stu2(uint2* p, uint2 v) {
+  if (COH) st64<true>(reinterpret_cast<uint64_t*>(p), uint64_t(v.x) | (uint64_t(v.y) << 32));
+  else *p = v;
+}
 
 // omega_m^e from the two-level table (e < m)
 __device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
@@ -226,34 +258,35 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
 // previous run (in digit order) of run (T, i1): same row, previous tile; first tile wraps to the
 // last tile of the previous row (cyclic: 2^p = 1)
+template <bool COH = false>
 __device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_t* cbuf, uint32_t T, uint32_t i1) {
   const uint32_t NT = pl.M2 / pl.C;
-  if (T > 0) return cbuf[size_t(T - 1) * pl.M1 + i1];
-  return cbuf[size_t(NT - 1) * pl.M1 + (i1 ? i1 - 1 : pl.M1 - 1)];
+  if (T > 0) return ld64<COH>(cbuf + size_t(T - 1) * pl.M1 + i1);
+  return ld64<COH>(cbuf + size_t(NT - 1) * pl.M1 + (i1 ? i1 - 1 : pl.M1 - 1));
 }
 
 // ---------------------------------------------------------------------------------------------
 // front: one work-group per tile T (C adjacent columns, all M1 rows)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
-                                                uint64_t* __restrict__ Wout) {
-  P2* X = reinterpret_cast<P2*>(smem_raw);
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x, T = blockIdx.x;
-  if (blockIdx.x >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);   // last half round: see kernels_v2.hip, boost_if_late (C4: -2.7 %)
+// body of the front sweep for tile T (shared by k_front and the one-launch kernel k_coop; no __restrict__ here: k_coop reads and writes
+// the same buffers in one launch).  sub: the small subtraction of a Lucas-Lehmer step, applied in the field to digit 0 (weight 1).
+template <bool COH>
+__device__ __forceinline__ void front_body(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint64_t* Wout, uint32_t T, uint32_t sub,
+                                           P2* X, uint32_t tid, uint32_t nthr) {
   const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
   const uint2* dg = reinterpret_cast<const uint2*>(digits) + size_t(T) * tile;
 
   for (uint32_t e = tid; e < tile; e += nthr) {
     const uint32_t i1 = e >> pl.logC, c = e & (C - 1), i2 = T * C + c;
-    uint2 d = dg[e];
+    uint2 d = ldu2<COH>(dg + e);
     const uint32_t sa = pl.SA[i1];
     if (cbuf_in && c < 2) {
       // deferred run carries (C >= 2): the carry word left by the previous run goes into the first digits
       // of this one (three masked digits, the remainder onto the fourth: adc4, marin.cl:203-212).  The two
       // threads that own the run's first two pairs each redo the four-digit chain and keep their pair.
-      uint64_t cin = carry_in_of(pl, cbuf_in, T, i1);
+      uint64_t cin = carry_in_of<COH>(pl, cbuf_in, T, i1);
       if (cin) {
-        const uint2 p0 = dg[i1 * C], p1 = dg[i1 * C + 1];
+        const uint2 p0 = ldu2<COH>(dg + i1 * C), p1 = ldu2<COH>(dg + i1 * C + 1);
         uint32_t dd[4] = {p0.x, p0.y, p1.x, p1.y};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -274,8 +307,9 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
     const uint32_t sb = pl.SB[2 * i2];
     digit_info(pl, sa, sb, w0, wr0);
     digit_info(pl, pl.SA[M1 + i1], sb, w1, wr1);
-    const uint64_t a0 = gf::mul_u32(gf::half(pl.TA[i1]), d.x << (wr0 ? 0 : 1));
+    uint64_t a0 = gf::mul_u32(gf::half(pl.TA[i1]), d.x << (wr0 ? 0 : 1));
     const uint64_t a1 = gf::mul_u32(gf::half(pl.TA[M1 + i1]), d.y << (wr1 ? 0 : 1));
+    if (sub && (T | e) == 0) a0 = gf::sub(a0, uint64_t(sub));
     X[e] = {a0, a1};
   }
   __syncthreads();
@@ -300,21 +334,26 @@ __global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __re
     const uint64_t tw = one ? gf::mul(pre_lo, pre_hi) : tw_lookup(pl, ex);
     const P2 x = X[e];
     const uint64_t twb = gf::mul(tw, one ? pre_tb : pl.TB[2 * i2]);
-    W[size_t(pos) * pl.M2 + i2] = {gf::mul(x.a, twb), gf::mul(x.b, twb)};
+    stp2<COH>(W + size_t(pos) * pl.M2 + i2, P2{gf::mul(x.a, twb), gf::mul(x.b, twb)});
   }
+}
+__global__ void __launch_bounds__(1024) k_front(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in,
+                                                uint64_t* __restrict__ Wout) {
+  if (blockIdx.x >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);   // last half round: see kernels_v2.hip, boost_if_late (C4: -2.7 %)
+  front_body<false>(pl, digits, cbuf_in, Wout, blockIdx.x, 0, reinterpret_cast<P2*>(smem_raw), threadIdx.x, blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
 // middle: one work-group per row.  mode 0: square, 1: multiply by image Y, 2: forward only.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
-                                                uint64_t* __restrict__ Wout, int mode, uint32_t sub) {
-  P2* X = reinterpret_cast<P2*>(smem_raw);
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x, row = blockIdx.x, M2 = pl.M2;
+template <bool COH>
+__device__ __forceinline__ void middle_body(const DevPlan& pl, const uint64_t* Win, const uint64_t* Yimg, uint64_t* Wout, int mode, uint32_t sub, uint32_t row,
+                                            P2* X, uint32_t tid, uint32_t nthr) {
+  const uint32_t M2 = pl.M2;
   const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * M2;
   P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * M2;
 
-  for (uint32_t e = tid; e < M2; e += nthr) X[e] = in[e];
+  for (uint32_t e = tid; e < M2; e += nthr) X[e] = ldp2<COH>(in + e);
   __syncthreads();
   // deferred small subtraction on a front image (digit 0 -> column 0, plane a of every row, weight 1)
   if (sub != 0 && tid == 0) X[0].a = gf::sub(X[0].a, uint64_t(sub));
@@ -328,7 +367,7 @@ __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __r
   }
   lds_pow2_dft<false>(X, M2, pl.logM2, 1, 1, 0, pl.UT2, M2, 1, pl.I4, tid, nthr);
   if (mode == 2) {
-    for (uint32_t e = tid; e < M2; e += nthr) out[e] = X[e];
+    for (uint32_t e = tid; e < M2; e += nthr) stp2<COH>(out + e, X[e]);
     return;
   }
   const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * M2;
@@ -349,7 +388,11 @@ __global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __r
   }
   __syncthreads();
   lds_pow2_dft<true>(X, M2, pl.logM2, 1, 1, 0, pl.UT2, M2, 1, pl.I4inv, tid, nthr);
-  for (uint32_t e = tid; e < M2; e += nthr) out[e] = X[e];
+  for (uint32_t e = tid; e < M2; e += nthr) stp2<COH>(out + e, X[e]);
+}
+__global__ void __launch_bounds__(1024) k_middle(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
+                                                uint64_t* __restrict__ Wout, int mode, uint32_t sub) {
+  middle_body<false>(pl, Win, Yimg, Wout, mode, sub, blockIdx.x, reinterpret_cast<P2*>(smem_raw), threadIdx.x, blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -368,15 +411,14 @@ __device__ __forceinline__ void run_carry_in(const DevPlan& pl, uint32_t sa, uin
   dd[3] += uint32_t(cin);
 }
 
-template <bool EXT>
-__global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
-                                              uint64_t* __restrict__ cbuf, uint32_t a, BackExt ext) {
-  P2* X = reinterpret_cast<P2*>(smem_raw);
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-  // blocks that share an XCD (b, b + 8, ...) take neighbouring tiles: the 64-byte pieces of a work-buffer line meet in one L2
-  // (same order as the register-resident back sweep; C4: 93.3 -> 90.4 us).  MI355_TUNE bit 0 switches it off.
-  const uint32_t T = (!(pl.tune & 1) && gridDim.x % 8 == 0) ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  if (blockIdx.x >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);   // last half round: see kernels_v2.hip, boost_if_late (C4: -2.7 %)
+// blocks that share an XCD (b, b + 8, ...) take neighbouring tiles: the 64-byte pieces of a work-buffer line meet in one L2
+// (same order as the register-resident back sweep; C4: 93.3 -> 90.4 us).  MI355_TUNE bit 0 switches it off.
+__device__ __forceinline__ uint32_t xcd_tile(const DevPlan& pl, uint32_t b, uint32_t groups) {
+  return (!(pl.tune & 1) && groups % 8 == 0) ? (b & 7) * (groups >> 3) + (b >> 3) : b;
+}
+template <bool EXT, bool COH>
+__device__ __forceinline__ void back_body(const DevPlan& pl, const uint64_t* Win, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& ext, uint32_t T,
+                                          P2* X, uint32_t tid, uint32_t nthr) {
   const uint32_t C = pl.C, M1 = pl.M1, tile = M1 * C;
   const P2* W = reinterpret_cast<const P2*>(Win);
 
@@ -385,7 +427,7 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
     const uint32_t k1 = freq1(pl, pos);
     const uint32_t ex = i2 * k1;   // i2 < M2, k1 < M1: below m, no reduction needed
     const uint64_t tw = tw_lookup(pl, ex ? pl.m - ex : 0);
-    const P2 x = W[size_t(pos) * pl.M2 + i2];
+    const P2 x = ldp2<COH>(W + size_t(pos) * pl.M2 + i2);
     const uint64_t twb = gf::mul(tw, pl.TBi[2 * i2]);   // one column factor per pair (see k_front)
     X[e] = {gf::mul(x.a, twb), gf::mul(x.b, twb)};
   }
@@ -437,11 +479,88 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
           carry = (r >> width) + chi * a;
         }
       }
-      dg[i1 * C + c] = make_uint2(out[0], out[1]);
+      stu2<COH>(dg + i1 * C + c, make_uint2(out[0], out[1]));
       if (EXT && ext.digits2) reinterpret_cast<uint2*>(ext.digits2)[size_t(T) * tile + size_t(i1) * C + c] = make_uint2(out[0], out[1]);
     }
-    cbuf[size_t(T) * M1 + i1] = carry;
+    st64<COH>(cbuf + size_t(T) * M1 + i1, carry);
     if (EXT && ext.digits2) ext.cbuf2[size_t(T) * M1 + i1] = carry;
+  }
+}
+template <bool EXT>
+__global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+                                              uint64_t* __restrict__ cbuf, uint32_t a, BackExt ext) {
+  if (blockIdx.x >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);   // last half round: see kernels_v2.hip, boost_if_late (C4: -2.7 %)
+  back_body<EXT, false>(pl, Win, digits, cbuf, a, ext, xcd_tile(pl, blockIdx.x, gridDim.x), reinterpret_cast<P2*>(smem_raw), threadIdx.x, blockDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One launch per squaring (or per run of squarings) for transforms whose tiles all fit on the chip at once: n <= 2^20 words has at
+// most 256 column tiles and 512 rows, a launch of the three kernels above lasts as long as ONE tile's dependent stream (5-6 us) plus
+// ~2 us to the next launch, and the chip's work is ~1 us per sweep.  k_coop runs front | rows | back of `count` squarings in one
+// cooperative launch (hipLaunchCooperativeKernel: every work-group is resident, so the barrier below cannot wait for a group that has
+// not started).  Reference: the same chain as three launches, forward1024_0 / sqr512 / backward1024_0, kernels/marin.cl:1190,1517,
+// engine_gpu.h:1591.
+//
+// Grid barrier: one flag word per work-group, written with its epoch once the group's hand-over stores are acknowledged; wave 0 of every
+// group polls all flags (one 4-byte agent-scope load per lane and 64 groups).  No read-modify-write on a shared word and no L2
+// write-back / invalidate: everything that crosses the barrier is accessed with sc1 (ld64 / st64 above).  A group that waits longer than kCoopTimeoutTicks (100 MHz
+// wall clock: 0.2 s) or sees the error word set raises it and leaves; every later barrier of every group then returns at once, so the
+// grid drains and the host reports the error (Engine::sync / the next call).
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kCoopTimeoutTicks = 20000000ull;
+
+__device__ __forceinline__ bool grid_sync(uint32_t* flags, uint32_t* err, uint32_t ngroups, uint32_t epoch) {
+  __shared__ uint32_t ok_sh;
+  // the sweeps' hand-over data travels in sc1 stores (st64<true>): once they are acknowledged (vmcnt = 0, which the workgroup-scope
+  // release waits for) they are at the memory side, where the sc1 loads of the next sweep find them -- no L2 maintenance here
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t0 = wall_clock64();
+    bool ok = true;
+    uint32_t spins = 0;
+    for (;;) {
+      bool here = true;
+      for (uint32_t g = threadIdx.x; g < ngroups; g += 64)
+        here = here && int32_t(__hip_atomic_load(&flags[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0;
+      if (__all(here)) break;
+      const bool bad = (++spins & 63u) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t0 > kCoopTimeoutTicks);
+      if (__any(bad)) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (threadIdx.x == 0) ok_sh = ok ? 1u : 0u;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return ok_sh != 0;
+}
+
+struct CoopArgs {
+  uint32_t* digits; uint64_t* cbuf; uint64_t* W;     // register (tile-major digits), its run carries, the work buffer
+  uint32_t* flags; uint32_t* err;                     // barrier words (one per work-group), error word
+  uint32_t a, sub, count, epoch0, carry_in;           // x <- (x^2 - sub?) ... : every squaring is square_mul(a) preceded by the pending "- sub"
+  uint32_t sub_next;                                  // subtraction folded into the front sweeps of squarings 2 .. count (Lucas-Lehmer runs)
+};
+
+__global__ void __launch_bounds__(1024) k_coop(DevPlan pl, CoopArgs ca) {
+  P2* X = reinterpret_cast<P2*>(smem_raw);
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x, G = gridDim.x;
+  const uint32_t NT = pl.M2 / pl.C, M1 = pl.M1;
+  uint32_t epoch = ca.epoch0;
+  for (uint32_t it = 0; it < ca.count; ++it) {
+    const uint64_t* cin = (it || ca.carry_in) ? ca.cbuf : nullptr;
+    const uint32_t sub = it ? ca.sub_next : ca.sub;
+    for (uint32_t t = b; t < NT; t += G) { front_body<true>(pl, ca.digits, cin, ca.W, xcd_tile(pl, t, NT), sub, X, tid, nthr); __syncthreads(); }
+    if (!grid_sync(ca.flags, ca.err, G, ++epoch)) return;
+    for (uint32_t r = b; r < M1; r += G) { middle_body<true>(pl, ca.W, nullptr, ca.W, 0, 0, r, X, tid, nthr); __syncthreads(); }
+    if (!grid_sync(ca.flags, ca.err, G, ++epoch)) return;
+    for (uint32_t t = b; t < NT; t += G) { back_body<false, true>(pl, ca.W, ca.digits, ca.cbuf, ca.a, BackExt(), xcd_tile(pl, t, NT), X, tid, nthr); __syncthreads(); }
+    if (it + 1 < ca.count && !grid_sync(ca.flags, ca.err, G, ++epoch)) return;
   }
 }
 
@@ -740,6 +859,31 @@ hipError_t configure_split(const DevPlan& pl) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_split_b), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_split_b), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+}
+// one cooperative launch for `count` squarings: supported when the generic kernels serve the plan with run carries folded into the front
+// sweep (C >= 2, no split columns) and a grid of max(tiles, rows) work-groups is resident at once
+static inline uint32_t coop_threads(const DevPlan& pl) { return std::max(block_for_small(pl, size_t(pl.M1) * pl.C), block_for_small(pl, pl.M2)); }
+static inline size_t coop_lds(const DevPlan& pl) { return std::max(size_t(pl.M1) * pl.C, size_t(pl.M2)) * 16 + 16; }
+uint32_t coop_groups(const DevPlan& pl, int device) {
+  if (pl.C < 2) return 0;
+  const size_t lds = coop_lds(pl);
+  if (lds > 160 * 1024) return 0;
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_coop), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) return 0;
+  int coop = 0, per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess || !coop) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop, int(coop_threads(pl)), lds) != hipSuccess || per_cu < 1) return 0;
+  const uint32_t want = std::max(pl.M2 / pl.C, pl.M1);
+  const uint32_t room = uint32_t(per_cu) * uint32_t(prop.multiProcessorCount);
+  return want <= room ? want : 0;   // a grid smaller than the tile count would serialise tiles inside a group: not the case this is for
+}
+hipError_t launch_coop(const DevPlan& pl, uint32_t groups, uint32_t* digits, uint64_t* cbuf, bool carry_in, uint64_t* W, uint32_t a, uint32_t sub, uint32_t sub_next,
+                       uint32_t count, uint32_t* flags, uint32_t* err, uint32_t epoch0, hipStream_t s) {
+  DevPlan plc = pl;
+  CoopArgs ca{digits, cbuf, W, flags, err, a, sub, count, epoch0, carry_in ? 1u : 0u, sub_next};
+  void* args[2] = {&plc, &ca};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_coop), dim3(groups), dim3(coop_threads(pl)), args, unsigned(coop_lds(pl)), s);
 }
 hipError_t launch_linear(const DevPlan& pl, const LinArgs& la, hipStream_t s) {
   const size_t runs = size_t(pl.M1) * (pl.M2 / pl.C);

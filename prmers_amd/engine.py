@@ -73,6 +73,7 @@ def load_library():
         "mi355_engine_addsub_copy": (C.c_int, [vp, sz, sz, sz, sz, sz, sz]),
         "mi355_engine_mul_add": (C.c_int, [vp, sz, sz, sz, u32]),
         "mi355_engine_square_mul_copy": (C.c_int, [vp, sz, sz, u32]),
+        "mi355_engine_square_mul_n": (C.c_int, [vp, sz, u32, sz, u32]),
         "mi355_engine_mul_copy": (C.c_int, [vp, sz, sz, sz, u32]),
         "mi355_crt_carry": (C.c_int, [u32, sz, u32, u32, vp, vp, vp, vp, sz, dp]),
         "mi355_crt_transform_size": (sz, [u32, u32]),
@@ -98,7 +99,7 @@ EXPORTS = [
     "mi355_engine_set_checkpoint", "mi355_engine_time_square_mul", "mi355_engine_kernel_count",
     "mi355_engine_kernel_name", "mi355_engine_algorithmic_bytes", "mi355_engine_selftest",
     "mi355_crt_carry", "mi355_crt_transform_size", "mi355_engine_describe", "mi355_crt_get_raw_digits", "mi355_crt_set_raw_digits",
-    "mi355_engine_addsub", "mi355_engine_addsub_copy", "mi355_engine_mul_add", "mi355_engine_square_mul_copy", "mi355_engine_mul_copy",
+    "mi355_engine_addsub", "mi355_engine_addsub_copy", "mi355_engine_mul_add", "mi355_engine_square_mul_copy", "mi355_engine_mul_copy", "mi355_engine_square_mul_n",
 ]
 
 
@@ -165,6 +166,9 @@ class Engine:
     def addsub_copy(self, s, d, s_copy, d_copy, a, b): self._ok(self.L.mi355_engine_addsub_copy(self.h, s, d, s_copy, d_copy, a, b))
     def mul_add(self, dst, mul_src, add_src, a=1): self._ok(self.L.mi355_engine_mul_add(self.h, dst, mul_src, add_src, a))
     def square_mul_copy(self, src, dst_copy, a=1): self._ok(self.L.mi355_engine_square_mul_copy(self.h, src, dst_copy, a))
+    def square_mul_n(self, src, count, a=1, sub=0):
+        """count x { src = src^2 * a; src -= sub }: one cooperative launch on the small transforms."""
+        self._ok(self.L.mi355_engine_square_mul_n(self.h, src, a, count, sub))
     def mul_copy(self, dst, src, dst_copy, a=1): self._ok(self.L.mi355_engine_mul_copy(self.h, dst, src, dst_copy, a))
 
     def is_equal(self, lhs, rhs):

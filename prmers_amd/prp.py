@@ -201,6 +201,20 @@ def shard_worktodo(lines, rank, world):
 # ---------------------------------------------------------------------------------------------
 # the driver
 # ---------------------------------------------------------------------------------------------
+def _square_n(eng, reg, count, sub=0):
+    """count x { reg = reg^2; reg -= sub }: one engine call where the engine has square_mul_n, else the loop it stands for."""
+    if count <= 0:
+        return
+    f = getattr(eng, "square_mul_n", None)
+    if f is not None and count > 1:
+        f(reg, count, 1, sub)
+        return
+    for _ in range(count):
+        eng.square_mul(reg)
+        if sub:
+            eng.sub(reg, sub)
+
+
 def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, max_iters=None,
                   log=None, ckpt_path=None, backup_every=0, resume=None, stop_after_s=None, on_check=None, should_stop=None,
                   backup_interval_s=None):
@@ -266,6 +280,7 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
         it, j = itersave + 1, jsave - 1
     state = None
     interrupted = False
+    batched = hasattr(eng, "square_mul_n")
 
     last_backup = [t_start]
 
@@ -285,10 +300,28 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
                 checkpoint(it)
             log("Interrupted, state saved at iteration %d j=%d" % (it, j))
             break
-        eng.square_mul(R0)
-        if not prp:
-            eng.sub(R0, 2)
-        done += 1
+        # the run of plain iterations up to the next event (Gerbicz-Li boundary, injected error, checkpoint, stop poll) goes to the
+        # engine as ONE call where it offers square_mul_n (one cooperative launch on the small transforms); `it` / `j` then name the
+        # last iteration of the run, as they would after that many turns of the reference's loop (RunPrpOrLlMarin.cpp:338-409)
+        r = 1
+        if batched:
+            r = (j % B + 1) if (prp and gerbicz) else (total - it)
+            r = min(r, total - it)
+            if erroriter > 0 and not errordone and erroriter > it:
+                r = min(r, erroriter - it)
+            if max_iters is not None:
+                r = min(r, max_iters - done)
+            if ckpt_path and backup_every:
+                r = min(r, backup_every - done % backup_every)
+            if ckpt_path and backup_interval_s is not None:
+                r = min(r, 256 - (done & 255))
+            if should_stop is not None or stop_after_s is not None:
+                r = min(r, 256)
+            r = max(r, 1)
+        _square_n(eng, R0, r, 0 if prp else 2)
+        it += r - 1
+        j -= r - 1
+        done += r
         if erroriter > 0 and it + 1 == erroriter and not errordone:
             errordone = True
             eng.sub(R0, 2)
@@ -302,14 +335,12 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
                 checkpass = 0
                 checks += 1
                 modB = B if p % B == 0 else p % B
-                for _ in range(B - modB - 1 if B > modB else 0):
-                    eng.square_mul(R3)
+                _square_n(eng, R3, B - modB - 1 if B > modB else 0)
                 if p % B == 0:
                     eng.mul(R3, RTMP)
                 else:
                     eng.square_mul(R3, 3)
-                for _ in range(modB):
-                    eng.square_mul(R3)
+                _square_n(eng, R3, modB)
                 # the reference compares two mpz read-backs (RunPrpOrLlMarin.cpp:363-366); here the engine compares the
                 # canonical forms on the device (canon.hip), 16 bytes over PCIe
                 same = eng.is_equal(R3, R1) if hasattr(eng, "is_equal") else eng.get_int(R3) == eng.get_int(R1)

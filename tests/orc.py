@@ -213,6 +213,11 @@ class OracleEngine:
     def set(self, dst, a): self.o.set(dst, a)
     def copy(self, dst, src): self.o.copy(dst, src)
     def square_mul(self, src, a=1): self.o.square_mul(src, a)
+    def square_mul_n(self, src, count, a=1, sub=0):   # the loop Engine.square_mul_n stands for (prp.py batches plain iterations through it)
+        for _ in range(count):
+            self.square_mul(src, a)
+            if sub:
+                self.sub(src, sub)
     def set_multiplicand(self, dst, src): self.o.set_multiplicand(dst, src)
     def mul(self, dst, src, a=1): self.o.mul(dst, src, a)
     def sub(self, src, a): self.o.sub(src, a)

@@ -1,0 +1,135 @@
+"""One-launch squarings of the small transforms (kernels.hip k_coop, Engine::square_mul_n; opt-in with MI355_COOP=1, the default is the
+three-launch chain, which is faster on MI355X: DESIGN.md 5.2c): the cooperative kernel against the oracle, against the three-launch chain
+and against Python integers; square_mul_n on both paths.  Reference chain: forward1024_0 / sqr512 /
+backward1024_0, kernels/marin.cl:1190,1517, engine_gpu.h:1591; caller loop RunPrpOrLlMarin.cpp:338-409.  Needs a real MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+def Engine(*a, **k):
+    from prmers_amd import Engine as E
+    return E(*a, **k)
+
+
+class env:
+    def __init__(self, **kv): self.kv = kv
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+# exponent, plan: two-level generic plans with runs of at least four digits (C >= 2), power-of-two and radix-5 columns, one tile .. 512 rows
+COOP_CASES = [(127, "m2=2,c=2"), (521, "m2=4,c=2"), (1801, "m2=8,c=4"), (3997, "m2=16,c=4"), (9941, "m2=64,c=8"), (9941, "m2=4,c=4"),
+              (13967, None), (44497, None), (102701, None), (400063, "m2=64,c=4"), (1001, "m2=2,c=2"), (2976221, None), (9815459, None),
+              (19000013, None)]
+
+
+@pytest.mark.parametrize("p,plan", COOP_CASES)
+def test_one_launch_squarings_match_the_oracle_and_the_three_launch_chain(p, plan):
+    rng = np.random.default_rng(p)
+    x0 = int.from_bytes(rng.bytes((p + 7) // 8), "little") % ((1 << p) - 1)
+    iters = 24 if p < 1000000 else 6
+    o = orc.Oracle(p, 2)
+    o.set_value(0, x0)
+    ref = Engine(p, 2, plan=plan)
+    with env(MI355_COOP=1):
+        e = Engine(p, 2, plan=plan)
+    with e, ref:
+        assert ":coop=" in e.describe() and ":coop=" not in ref.describe(), (e.describe(), ref.describe())
+        assert e.n == o.n
+        e.set_int(0, x0); ref.set_int(0, x0)
+        for it in range(iters):
+            a = 3 if it % 5 == 4 else 1
+            e.square_mul(0, a); ref.square_mul(0, a); o.square_mul(0, a)
+            if it % 6 == 0 or it >= iters - 2:
+                d = e.digits(0)
+                assert np.array_equal(d, o.digits(0)), (p, plan, it)
+                assert np.array_equal(d, ref.digits(0)), (p, plan, it)
+        # a run of squarings in ONE launch, then the Lucas-Lehmer form (x^2 - 2 folded into the next front sweep)
+        e.square_mul_n(0, 17); ref.square_mul_n(0, 17)
+        for _ in range(17): o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0)) and np.array_equal(ref.digits(0), o.digits(0))
+        e.square_mul_n(0, 9, 1, 2); ref.square_mul_n(0, 9, 1, 2)
+        for _ in range(9): o.square_mul(0); o.sub(0, 2)
+        assert np.array_equal(e.digits(0), o.digits(0)) and np.array_equal(ref.digits(0), o.digits(0))
+        assert e.res64(0) == o.res64(0)
+        # pending state survives the other operations: copy, multiplicand, mul, add
+        e.sub(0, 5); o.sub(0, 5)
+        e.copy(1, 0); o.copy(1, 0)
+        e.square_mul_n(1, 3); [o.square_mul(1) for _ in range(3)]
+        e.set_multiplicand(1, 1); o.set_multiplicand(1, 1)
+        e.mul(0, 1); o.mul(0, 1)
+        e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+
+
+@pytest.mark.parametrize("coop", [0, 1])
+@pytest.mark.parametrize("p,prime", [(521, True), (523, False), (2203, True), (9941, True), (9949, False), (11213, True)])
+def test_lucas_lehmer_in_runs_of_squarings(p, prime, coop):
+    """s <- s^2 - 2 from 4, p - 2 times, as three calls of square_mul_n (unit_tests.sh:5-14 holds the verdicts)."""
+    with env(MI355_COOP=coop):
+        e = Engine(p, 2)
+    with e:
+        assert (":coop=" in e.describe()) == bool(coop)
+        e.set(0, 4)
+        total = p - 2
+        for part in (total // 3, total // 3, total - 2 * (total // 3)):
+            e.square_mul_n(0, part, 1, 2)
+        v = e.get_int(0)
+        assert (v == 0) == prime
+
+
+def test_prp_m11213_residues_of_the_reference_in_runs():
+    """unit_tests.sh:166-178: Res64 of 3^(2^k) mod M11213 at k = 1000 .. 11000 -- a thousand squarings per launch."""
+    p = 11213
+    with env(MI355_COOP=1):
+        e = Engine(p, 2)
+    with e:
+        assert ":coop=" in e.describe()
+        e.set(0, 3)
+        for k, want in sorted((int(k), v) for k, v in GOLD["m11213_intermediate_res64"].items() if k != "src"):
+            e.square_mul_n(0, 1000)
+            assert "%016X" % e.res64(0) == want.upper(), k
+
+
+def test_c2_exponent_a_gerbicz_block_in_one_launch():
+    """BASELINE configs[1] (p = 9815459): one Gerbicz-Li block -- B = 3132 squarings in one launch, d <- d x, and the verification of the
+    block (prp.py) -- against the same block on the three-launch chain."""
+    from prmers_amd import prp
+    p = 9815459
+    B = int(p ** 0.5)
+    ref = Engine(p, prp.REGISTERS)
+    with env(MI355_COOP=1):
+        e = Engine(p, prp.REGISTERS)
+    with e, ref:
+        assert ":coop=256" in e.describe()
+        msgs = []
+        r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, max_iters=2 * B + 7, log=msgs.append)
+        r0 = prp.run_prp_or_ll(ref, p, "prp", checklevel=1, max_iters=2 * B + 7)
+        assert r["gerbicz_checks"] >= 1 and r["gerbicz_errors"] == 0 and any("Check passed" in m for m in msgs)
+        assert r["res64"] == r0["res64"] and r["res2048"] == r0["res2048"]
+        assert e.is_equal(0, 0) and np.array_equal(e.digits(0), ref.digits(0))
+
+
+def test_an_injected_error_is_caught_on_the_one_launch_path():
+    from prmers_amd import prp
+    p = 86243
+    with env(MI355_COOP=1):
+        e = Engine(p, prp.REGISTERS)
+    with e:
+        msgs = []
+        r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, erroriter=1500, log=msgs.append)
+        assert r["is_prime"] and r["gerbicz_errors"] == 1 and any("Check FAILED" in m for m in msgs)

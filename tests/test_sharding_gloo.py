@@ -59,7 +59,7 @@ def _worker(rank, world, port, q, scenario):
 
             def stop():
                 polls[0] += 1
-                return polls[0] > 200
+                return polls[0] > 12
             res1, st1 = launch.run_sharded(WORKTODO, lambda p: orc.OracleEngine(p, prp.REGISTERS), checklevel=1, should_stop=stop, ckpt_dir=d)
             assert st1["all_ok"] == 1 and all((not r["complete"]) for r in res1 if r["exponent"] != 127), (st1, res1)
             assert any(r.get("interrupted") for r in res1)
@@ -135,10 +135,12 @@ def test_interrupt_checkpoints_every_rank_and_a_second_launch_resumes():
     expected = sorted([(127, "prp", True, 0, None), (607, "ll", True, 0, None), (521, "prp", True, 1, None), (1001, "prp", False, 1, None)])
     for rank, res, status, _ in _run("interrupt"):
         assert sorted(res) == expected and status["all_ok"] == 1
-        # the 201st poll of a rank stops it (one poll per entry + one per iteration): rank 0 finished 127 and got 71 iterations into
-        # 607, rank 1 got 199 into 521 and never started 1001; the second launch resumes both from their checkpoints
-        assert status["first_run_iterations"] == 127 + 71 + 199
-        assert status["iterations"] == 605 + 521 + 1001 + 127     # (127 has no checkpoint after its last iteration: it runs again)
+        # the 13th poll of a rank stops it (one poll per entry + one per run of plain iterations, prp.py: up to the next Gerbicz-Li boundary,
+        # 256 at most): rank 0 finished 127 and got part of the way into 607, rank 1 part of the way into 521 and never started 1001; the
+        # second launch resumes both from their checkpoints (127 has no checkpoint after its last iteration: it runs again)
+        total = 605 + 521 + 1001 + 127
+        assert 127 < status["first_run_iterations"] < 127 + 605 + 521
+        assert status["iterations"] == total     # every entry reports the iteration it ended on
 
 
 def test_launcher_command_line_dry_run(tmp_path):
