@@ -38,7 +38,7 @@ struct Grid {
   uint64_t r61[9], r61i[9], s61, c3_61;               // odd-root powers r^e, their inverses, 1 / (odd h), (w3 - w3^2) / 2
   uint32_t r31[9], r31i[9], s31, c3_31;
   uint32_t mm, pm, lpm61, lpm31;                      // m mod odd; p m mod n and its images l61 (p m) mod 61, l31 (p m) mod 31
-  uint32_t tune;                                      // MI355_CRT_TUNE (A/B runs): bit 0 plain tile order in the column kernels
+  uint32_t tune;                                      // MI355_CRT_TUNE (A/B runs): bit 0 plain tile order in the column kernels, bit 1 back and carry as two kernels
 };
 
 template <class F>
@@ -156,6 +156,110 @@ __global__ void __launch_bounds__(256) k_back(Grid gr, const F61::C* __restrict_
     *reinterpret_cast<uint2*>(out31 + j) = make_uint2(S31[2 * a][tid], S31[2 * a1 + 1][tid]);
     a += gr.mm; if (a >= ODD) a -= ODD;
   }
+}
+
+// ---- back + carry in one kernel (round 3): the inverse odd axis of 256 slots, then the unweight + Garner + carry sweep of crt_carry.hip on
+// the 2 x 256 x ODD digits they hold, straight out of LDS -- the unweighted residues (12 bytes a word) no longer make a round trip
+// through HBM between k_back and k_crt_runs_linked, and one launch goes.  The slots s0 .. s0 + 255 of a work-group hold ODD ranges of
+// 512 consecutive digits, [2 s0 + m t, 2 s0 + 512 + m t): one thread per run of kRun digits (64 runs a range, ODD x 64 virtual threads on
+// 256 real ones), sequential carry inside a run, run-to-run hand-over through LDS inside a range exactly as in k_crt_runs_linked;
+// edge_out[3 (ODD g + t) ..] = 128-bit carry and leftover of the last run of range t, folded into the following range by
+// k_crt_range_edges (n / 512 threads).  Reference: third_party/aevum/src/cl/carry.cl:506-588 (carry), fft-middle.cl:663-720 (pfaDft).
+template <int ODD>
+__global__ void __launch_bounds__(256) k_back_carry(Geom g, Grid gr, const F61::C* __restrict__ Z61, const F31::C* __restrict__ Z31, uint64_t* __restrict__ digits,
+                                                    uint64_t* __restrict__ edge_out) {
+  __shared__ uint64_t S61[2 * ODD][256];
+  __shared__ uint32_t S31[2 * ODD][256];
+  __shared__ uint64_t Clo[256], Chi[256], Rs[256];
+  const uint32_t tid = threadIdx.x, s0 = blockIdx.x * 256, s = s0 + tid;   // h is a multiple of 256 on this path (checked by the launcher)
+  {
+    F61::C in61[ODD]; F31::C in31[ODD];
+#pragma unroll
+    for (int k = 0; k < ODD; ++k) { in61[k] = Z61[size_t(k) * gr.h + s]; in31[k] = Z31[size_t(k) * gr.h + s]; }
+    dft_odd<F61, ODD>(in61, gr.r61i, F61::neg(gr.c3_61));
+    dft_odd<F31, ODD>(in31, gr.r31i, F31::neg(gr.c3_31));
+#pragma unroll
+    for (int k = 0; k < ODD; ++k) {   // row k at this slot: re = the row's even position 2 s, im = the odd one
+      const F61::C o61 = cscale<F61>(in61[k], gr.s61); const F31::C o31 = cscale<F31>(in31[k], gr.s31);
+      S61[2 * k][tid] = o61.re; S61[2 * k + 1][tid] = o61.im; S31[2 * k][tid] = o31.re; S31[2 * k + 1][tid] = o31.im;
+    }
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < uint32_t(ODD) * 64u; base += 256u) {
+    const uint32_t vt = base + tid, t = vt >> 6, r = tid & 63u;   // range, run inside the range (base is a multiple of 256)
+    const bool live = vt < uint32_t(ODD) * 64u;
+    uint64_t out[kRun]; uint32_t wd[kRun];
+    unsigned __int128 carry = 0;
+    uint32_t j0 = 0;
+    if (live) {
+      const uint32_t sl0 = 4u * r;
+      j0 = 2u * (s0 + sl0) + gr.m * t;
+      DigitWalk dw; dw.start(g, j0);
+      const uint32_t a0 = (2u * (s0 + sl0) + gr.mm * t) % uint32_t(ODD);   // row of digit j0 (j mod ODD with m = mm mod ODD)
+#pragma unroll
+      for (int k = 0; k < kRun; ++k) {
+        const uint32_t sl = sl0 + uint32_t(k >> 1);
+        const uint32_t a = (a0 + uint32_t(k)) % uint32_t(ODD);            // digit j0 + k sits in row (j0 + k) mod ODD
+        const uint32_t plane = 2u * a + uint32_t(k & 1);                   // even position: re, odd position: im
+        const uint64_t x61 = rot61(S61[plane][sl], dw.unweight61());
+        const uint32_t x31 = rot31(S31[plane][sl], dw.unweight31());
+        const uint64_t d = x61 >= x31 ? x61 - x31 : x61 + M61 - x31;       // Garner, as in k_crt_runs
+        const uint64_t tt = mul61(d, g.inv31);
+        const unsigned __int128 v = ((unsigned __int128)tt << 31) - tt + x31;
+        const unsigned __int128 sum = v * g.a + carry;
+        wd[k] = dw.width(g);
+        out[k] = uint64_t(sum) & ((uint64_t(1) << wd[k]) - 1);
+        carry = sum >> wd[k];
+        dw.next(g);
+      }
+    }
+    Clo[tid] = uint64_t(carry); Chi[tid] = uint64_t(carry >> 64);
+    __syncthreads();
+    unsigned __int128 in = r ? (((unsigned __int128)Chi[tid - 1] << 64) | Clo[tid - 1]) : 0;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < kRun; ++k) {
+        const unsigned __int128 sum = (unsigned __int128)out[k] + in;
+        out[k] = uint64_t(sum) & ((uint64_t(1) << wd[k]) - 1);
+        in = sum >> wd[k];
+      }
+    }
+    Rs[tid] = uint64_t(in);
+    __syncthreads();
+    if (live) {
+      if (r) out[0] += Rs[tid - 1];
+      ulonglong2* po = reinterpret_cast<ulonglong2*>(digits + j0);
+#pragma unroll
+      for (int k = 0; k < kRun / 2; ++k) po[k] = make_ulonglong2(out[2 * k], out[2 * k + 1]);
+      if (r == 63u) {
+        uint64_t* eo = edge_out + 3 * (size_t(blockIdx.x) * ODD + t);
+        eo[0] = uint64_t(carry); eo[1] = uint64_t(carry >> 64); eo[2] = uint64_t(in);
+      }
+    }
+    __syncthreads();   // Clo / Chi / Rs are reused by the next ranges
+  }
+}
+// first run of every range: the carry of the range before it in digit order (same t of the previous work-group; the last group's range t - 1
+// for the first group; cyclically, 2^p = 1) runs through its digits, the leftovers go in front of this run and of the next one without
+// further propagation (weak carry) -- k_crt_edges for the ranges of k_back_carry
+__global__ void __launch_bounds__(256) k_crt_range_edges(Geom g, Grid gr, uint64_t* __restrict__ digits, const uint64_t* __restrict__ edge) {
+  const uint32_t idx = blockIdx.x * 256 + threadIdx.x, G = gr.h >> 8, odd = gr.odd;
+  if (idx >= G * odd) return;
+  const uint32_t grp = idx / odd, t = idx - grp * odd;
+  const uint32_t prev = grp ? (grp - 1) * odd + t : (G - 1) * odd + (t ? t - 1 : odd - 1);
+  unsigned __int128 carry = ((unsigned __int128)edge[3 * size_t(prev) + 1] << 64) | edge[3 * size_t(prev)];
+  const uint32_t j0 = 512u * grp + gr.m * t;
+  DigitWalk dw; dw.start(g, j0);
+  for (int k = 0; k < kRun; ++k) {
+    const uint32_t width = dw.width(g);
+    const unsigned __int128 sum = (unsigned __int128)digits[j0 + k] + carry;
+    digits[j0 + k] = uint64_t(sum) & ((uint64_t(1) << width) - 1);
+    carry = sum >> width;
+    if (carry == 0) break;
+    dw.next(g);
+  }
+  digits[j0] += edge[3 * size_t(prev) + 2];
+  if (carry) digits[j0 + kRun] += uint64_t(carry);   // (a range has 512 digits: still inside it)
 }
 
 // ---- one pass of the row transforms --------------------------------------------------------------------------------------
@@ -667,6 +771,16 @@ void CrtEngine::launch_transform(size_t reg, int mode, size_t other, uint32_t a,
     launch_rows<F61>(gr, im.Z61, im.U61, true, s);
     launch_rows<F31>(gr, im.Z31, im.U31, true, s);
     mark();
+  }
+  // back + carry fused (k_back_carry) wherever a work-group has whole ranges of 512 digits; MI355_CRT_TUNE bit 1: the two-kernel form
+  if (gr.odd > 1 && (gr.h & 255u) == 0 && !(gr.tune & 2u)) {
+    const dim3 ggroups(gr.h >> 8), gedges((uint32_t(gr.h >> 8) * gr.odd + 255) / 256);
+    if (gr.odd == 3) hipLaunchKernelGGL((crt::k_back_carry<3>), ggroups, b256, 0, s, g, gr, im.Z61, im.Z31, x, im.carry);
+    else hipLaunchKernelGGL((crt::k_back_carry<9>), ggroups, b256, 0, s, g, gr, im.Z61, im.Z31, x, im.carry);
+    mark();   // slot k_back: the fused kernel; slot k_crt_carry: the range edges
+    hipLaunchKernelGGL(crt::k_crt_range_edges, gedges, b256, 0, s, g, gr, x, im.carry);
+    mark();
+    return;
   }
   switch (gr.odd) {
     case 1: hipLaunchKernelGGL((crt::k_back<1>), gslots, b256, 0, s, gr, im.Z61, im.Z31, im.w61, im.w31); break;

@@ -44,6 +44,26 @@ def test_square_mul_matches_the_oracle_digit_for_digit(p, odd, n, plan):
         assert e.res64(0) == o.value() & ((1 << 64) - 1)
 
 
+@pytest.mark.parametrize("p,odd,n", [(756839, 9, 9 << 12), (1257787, 3, 3 << 14), (37156667, 9, 9 << 18)])
+def test_fused_back_and_carry_against_the_two_kernel_form(p, odd, n, monkeypatch):
+    """k_back_carry (inverse odd axis + unweight + Garner + carry out of LDS, ranges of 512 digits per work-group) against k_back +
+    k_crt_runs_linked (MI355_CRT_TUNE bit 1) and the oracle: the weakly carried digit vectors may differ, the residues may not"""
+    rng = np.random.default_rng(p)
+    with CrtEngine(p, odd, n) as e:
+        monkeypatch.setenv("MI355_CRT_TUNE", "2")
+        with CrtEngine(p, odd, n) as two:
+            o = orc_crt.OracleCrt(p, odd, n)
+            w = o.widths().astype(np.uint64)
+            start = rng.integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))
+            start[::512] = (np.uint64(1) << w[::512]) - np.uint64(1)          # all-ones digits at the range boundaries: carries cross them
+            e.set_digits(0, start); two.set_digits(0, start); o.set_digits(start)
+            for it, a in enumerate((1, 3, 1, 1, 1)):
+                e.square_mul(0, a); two.square_mul(0, a); o.square_mul(a)
+                d = e.raw_digits(0)
+                assert np.array_equal(d, two.raw_digits(0)) and np.array_equal(d, o.digits()), (p, odd, it)
+            assert e.is_equal(0, 0) and e.res64(0) == two.res64(0)
+
+
 def test_both_kernel_sets_agree(monkeypatch):
     """the same squarings on the radix-8 row kernels and on the generic LDS radix-2 ones (MI355_CRT_KERNELS=generic)"""
     p, odd, n = 13466917, 9, 9 << 16
