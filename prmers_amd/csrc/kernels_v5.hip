@@ -1,0 +1,340 @@
+// gfx950 kernels, register-resident radix-5 column set ("v5"): column tiles of M1 = 1280 = 5 x 256 with C = 4 -- the columns of n = 5 2^21
+// (BASELINE configs[3] on the Goldilocks path), 5 2^22 and 5 2^23.  Reference: forward80_0 / backward80_0, kernels/marin.cl:1019-1040,
+// engine_gpu.h:1619.  Helpers shared with kernels_v2.hip live in kernels_v2_common.hpp.
+#include "kernels_v2_common.hpp"
+
+namespace mi355 {
+
+// ---------------------------------------------------------------------------------------------
+// Columns of M1 = 1280 = 5 x 256 (n = 5 * 2^21: BASELINE configs[3] on the Goldilocks path), C = 4 pairs per run: one tile
+// of 5120 pairs per work-group of 640 threads, 8 pairs per thread, the radix-5 stage on 512 threads with 10.
+// The reference serves this size with forward80_0 / backward80_0 (kernels/marin.cl:1019-1040, engine_gpu.h:1619).
+//   i1 = 256 d0 + r,  r = 64 e1 + 8 e2 + e3;  column frequency k = k0 + 5 kr,  kr = k1 + 4 k2 + 32 k3
+//   L   thread t: runs i1 = t, t + 640 (digits -> carry-in -> weight)
+//   A   thread u < 512: groups g = u, u + 512 (r = g / 4, c = g % 4): DFT5 over d0, twiddle omega_1280^(r k0)
+//   B1  thread (k0 | e2 | e3 | c/2): DFT4 over e1, twiddle omega_256^(k1 (8 e2 + e3))
+//   B2  thread (k0 | k1 | e3 | c):   DFT8 over e2, twiddle omega_64^(k2 e3)
+//   B3  thread (k0 | k1 | k2 | c):   DFT8 over e3, then the four-step twiddle chain (ratio omega_m^(160 i2)) and the store to
+//       row k0 256 + bitrev8(kr), the row order of kernels.hip freq1
+// The factor 5 leaves no digit that is uniform over a wavefront, so the seams inside the power-of-two part are table
+// multiplications (omega_1280 powers from UT1) instead of the compile-time shifts of the 512 R shapes.  LDS carries one
+// plane (8 bytes per slot) at a time: 46 KiB per work-group, so that two of them share a CU.
+// The back sweep is the mirror image, ending with the unweighting and the carry along the thread's two runs.
+// ---------------------------------------------------------------------------------------------
+namespace v5 {
+constexpr uint32_t kThreads = 640, kTile = 5120, kM1 = 1280;
+// Launched with 768 threads: twelve waves spread evenly over the four SIMDs of a CU, the last two leave at once.  A work-group of ten waves
+// (3 + 3 + 2 + 2) is not placed next to a resident one for up to 17 us after a slot has become free (profiles/r03_probe_c4.md: 44 % of
+// the dispatches of a launch, a CU then runs one group for half of its time); twelve are placed within 2 us like the 512-thread groups.
+constexpr uint32_t kLaunchThreads = 768;
+constexpr uint32_t kPlaneWords = kTile + kTile / 32 + 8;
+// the exchange plane, then a copy of the omega_1280 table (10 KiB): the seams of this shape are table multiplications and their roots
+// come out of LDS (~100 cycles) instead of L2 (several hundred, exposed at every stage)
+constexpr uint32_t kLdsBytes = (kPlaneWords + kM1) * 8;
+__device__ __forceinline__ uint32_t ph(uint32_t i) { return i + (i >> 5); }
+__device__ __forceinline__ const uint64_t* stage_roots(const DevPlan& pl, uint64_t* X) {
+  uint64_t* R = X + kPlaneWords;
+  for (uint32_t i = threadIdx.x; i < kM1; i += kThreads) R[i] = pl.UT1[i];
+  return R;   // visible after the first barrier of the first exchange
+}
+
+// write 8 (or 10) values to element ids wi[], read ids ri[]; one plane after the other
+template <int NW, int NR, class WI, class RI>
+__device__ __forceinline__ void exchange(uint64_t* X, const v2::P2* in, v2::P2* out, bool writer, bool reader, WI wi, RI ri) {
+  v2::lds_barrier();
+  if (writer) { _Pragma("unroll") for (int k = 0; k < NW; ++k) X[ph(wi(k))] = in[k].a; }
+  v2::lds_barrier();
+  uint64_t ta[NR];
+  if (reader) { _Pragma("unroll") for (int k = 0; k < NR; ++k) ta[k] = X[ph(ri(k))]; }
+  v2::lds_barrier();
+  if (writer) { _Pragma("unroll") for (int k = 0; k < NW; ++k) X[ph(wi(k))] = in[k].b; }
+  v2::lds_barrier();
+  if (reader) { _Pragma("unroll") for (int k = 0; k < NR; ++k) out[k] = {ta[k], X[ph(ri(k))]}; }
+}
+
+__device__ __forceinline__ void dft5p(v2::P2 (&x)[5], const uint64_t (&c5)[4], bool inverse) {
+  // kernels.hip dft5, on the two planes (Winograd: 4 table multiplications + one shift per plane)
+  using v2::P2;
+  auto add = [](P2 p, P2 q) { return P2{gf::add(p.a, q.a), gf::add(p.b, q.b)}; };
+  auto sub = [](P2 p, P2 q) { return P2{gf::sub(p.a, q.a), gf::sub(p.b, q.b)}; };
+  auto mul = [](P2 p, uint64_t w) { return P2{gf::mul(p.a, w), gf::mul(p.b, w)}; };
+  const P2 t1 = add(x[1], x[4]), t2 = add(x[2], x[3]), t3 = sub(x[1], x[4]), t4 = sub(x[2], x[3]);
+  const P2 t5 = add(t1, t2);
+  const P2 A = add(x[0], P2{gf::mul_pow2(t5.a, 94), gf::mul_pow2(t5.b, 94)});
+  const P2 m2 = mul(sub(t1, t2), c5[0]);
+  const P2 B1 = add(A, m2), B2 = sub(A, m2);
+  const P2 m3 = mul(add(t3, t4), c5[1]), m4 = mul(t4, c5[2]), m5 = mul(t3, c5[3]);
+  const P2 Pp = add(m3, m4), Q = sub(m5, m3);
+  x[0] = add(x[0], t5);
+  if (!inverse) { x[1] = add(B1, Pp); x[4] = sub(B1, Pp); x[2] = add(B2, Q); x[3] = sub(B2, Q); }
+  else          { x[1] = sub(B1, Pp); x[4] = add(B1, Pp); x[2] = sub(B2, Q); x[3] = add(B2, Q); }
+}
+
+__device__ __forceinline__ uint32_t brev8(uint32_t k) { return __brev(k) >> 24; }
+
+__global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in, uint32_t sub,
+                                                   uint64_t* __restrict__ Wout) {
+  using v2::P2;
+  if (threadIdx.x >= kThreads) return;   // the two padding waves (kLaunchThreads): ended waves do not count at a barrier
+  uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
+  const uint32_t t = threadIdx.x, T = PROBE_BLOCK(pl);
+  v2::boost_if_late(pl.boost_tiles);
+  PROBE_BEGIN(pl)
+  const uint64_t* __restrict__ UT = stage_roots(pl, X);
+  // ---- L: the thread's two runs ----
+  P2 x[8];
+  {
+    const uint32_t di = pl.DI[size_t(T) * kThreads + t];
+    const uint32_t nowrap = ~di;
+#pragma unroll
+    for (int d1 = 0; d1 < 2; ++d1) {
+      const uint32_t i1 = t + kThreads * d1;
+      uint32_t dg[8];
+      {
+        const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * kM1 + i1) * 2;
+        const uint4 v0 = src[0], v1 = src[1];
+        dg[0] = v0.x; dg[1] = v0.y; dg[2] = v0.z; dg[3] = v0.w; dg[4] = v1.x; dg[5] = v1.y; dg[6] = v1.z; dg[7] = v1.w;
+      }
+      if (cbuf_in) v2::apply_carry_in<8>(pl, di, d1, v2::carry_in_of(pl, cbuf_in, T, i1), dg);
+      const uint64_t tah = gf::half(pl.TA[i1]), tah1 = gf::half(pl.TA[kM1 + i1]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = d1 * 8 + 2 * c;
+        x[d1 * 4 + c] = {gf::mul_u32(tah, dg[2 * c] << ((nowrap >> (2 * idx + 1)) & 1u)), gf::mul_u32(tah1, dg[2 * c + 1] << ((nowrap >> (2 * idx + 3)) & 1u))};
+      }
+      if (sub != 0 && T == 0 && i1 == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));
+    }
+  }
+  // ---- A: DFT5 over d0 ----
+  P2 y[10];
+  exchange<8, 10>(X, x, y, true, t < 512,
+                  [&](int k) { return (t + kThreads * (k >> 2)) * 4 + (k & 3); },
+                  [&](int k) { const uint32_t g = t + 512 * (k / 5); return (256 * (k % 5) + (g >> 2)) * 4 + (g & 3); });
+  if (t < 512) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t r = (t + 512 * q) >> 2;
+      P2 z[5] = {y[5 * q], y[5 * q + 1], y[5 * q + 2], y[5 * q + 3], y[5 * q + 4]};
+      dft5p(z, pl.W5c, false);
+#pragma unroll
+      for (int k0 = 1; k0 < 5; ++k0) z[k0] = v2::p2_mul(z[k0], UT[r * k0]);
+#pragma unroll
+      for (int k0 = 0; k0 < 5; ++k0) y[5 * q + k0] = z[k0];
+    }
+  }
+  // ---- B1: DFT4 over e1 ----
+  {
+    const uint32_t chi = t & 1, e3 = (t >> 1) & 7, e2 = (t >> 4) & 7, k0 = t >> 7;
+    exchange<10, 8>(X, y, x, t < 512, true,
+                    [&](int k) { const uint32_t g = t + 512 * (k / 5); return ((k % 5) * 256 + (g >> 2)) * 4 + (g & 3); },
+                    [&](int k) { return (k0 * 256 + 64 * (k >> 1) + 8 * e2 + e3) * 4 + 2 * chi + (k & 1); });
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      v2::dft4<false>(x[cl].a, x[2 + cl].a, x[4 + cl].a, x[6 + cl].a);
+      v2::dft4<false>(x[cl].b, x[2 + cl].b, x[4 + cl].b, x[6 + cl].b);
+    }
+    const uint32_t rr = 8 * e2 + e3;
+#pragma unroll
+    for (int k1 = 1; k1 < 4; ++k1) {
+      const uint64_t w = UT[5 * k1 * rr];   // omega_256 = omega_1280^5
+      x[2 * k1] = v2::p2_mul(x[2 * k1], w); x[2 * k1 + 1] = v2::p2_mul(x[2 * k1 + 1], w);
+    }
+    // ---- B2: DFT8 over e2 ----
+    P2 z[8];
+    const uint32_t c = t & 3, f3 = (t >> 2) & 7, f1 = (t >> 5) & 3, f0 = t >> 7;   // reader (k0 | k1 | e3 | c)
+    exchange<8, 8>(X, x, z, true, true,
+                   [&](int k) { return (((k0 * 4 + (k >> 1)) * 8 + e2) * 8 + e3) * 4 + 2 * chi + (k & 1); },
+                   [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; });
+    v2::dft8p<false, 1>(z);
+#pragma unroll
+    for (int k2 = 1; k2 < 8; ++k2) z[k2] = v2::p2_mul(z[k2], UT[20 * k2 * f3]);   // omega_64 = omega_1280^20
+    z[0] = {gf::fold(z[0].a), gf::fold(z[0].b)};
+    // ---- B3: DFT8 over e3 ----
+    const uint32_t g2 = (t >> 2) & 7;   // reader (k0 | k1 | k2 | c): same decode, e3's place holds k2
+    exchange<8, 8>(X, z, x, true, true,
+                   [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; },
+                   [&](int k) { return (((f0 * 4 + f1) * 8 + g2) * 8 + k) * 4 + c; });
+    v2::dft8p<false, 2>(x);
+    const uint32_t i2 = 4 * T + c;
+    uint64_t ca = pl.F0f[size_t(T) * kThreads + t];
+    const uint64_t B = pl.FBf[i2];
+    P2* W = reinterpret_cast<P2*>(Wout);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t row = f0 * 256 + brev8(f1 + 4 * g2 + 32 * j);
+      W[size_t(row) * pl.M2 + i2] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)};
+      if (j < 7) ca = gf::mul(ca, B);
+    }
+  }
+  PROBE_END(pl)
+}
+
+template <bool EXT>
+__global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits, uint64_t* __restrict__ cbuf,
+                                                   uint32_t a, uint64_t scale, BackExt ext) {
+  using v2::P2;
+  if (threadIdx.x >= kThreads) return;   // the two padding waves (kLaunchThreads)
+  uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
+  const uint32_t t = threadIdx.x, T = v2::tile_of_block(pl, PROBE_BLOCK(pl), PROBE_GRID(pl));
+  v2::boost_if_late(pl.boost_tiles);
+  PROBE_BEGIN(pl)
+  const uint64_t* __restrict__ UT = stage_roots(pl, X);
+  const uint32_t c = t & 3, g2 = (t >> 2) & 7, f1 = (t >> 5) & 3, f0 = t >> 7, f3 = g2;
+  P2 x[8], z[8];
+  {
+    const uint32_t i2 = 4 * T + c;
+    uint64_t ca = pl.F0i[size_t(T) * kThreads + t];
+    const uint64_t B = pl.FBi[i2];
+    if (scale != 1) ca = gf::mul(ca, scale);
+    const P2* W = reinterpret_cast<const P2*>(Win);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = W[size_t(f0 * 256 + brev8(f1 + 4 * g2 + 32 * j)) * pl.M2 + i2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)}; if (j < 7) ca = gf::mul(ca, B); }
+  }
+  v2::dft8p<true, 2>(x);   // k3 -> e3; multiplied by the seam next
+  exchange<8, 8>(X, x, z, true, true,
+                 [&](int k) { return (((f0 * 4 + f1) * 8 + g2) * 8 + k) * 4 + c; },
+                 [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; });
+#pragma unroll
+  for (int k2 = 1; k2 < 8; ++k2) { const uint32_t e = 20 * k2 * f3; z[k2] = v2::p2_mul(z[k2], UT[e ? kM1 - e : 0]); }
+  z[0] = {gf::fold(z[0].a), gf::fold(z[0].b)};
+  v2::dft8p<true, 2>(z);   // k2 -> e2
+  const uint32_t chi = t & 1, e3 = (t >> 1) & 7, e2 = (t >> 4) & 7, k0 = t >> 7;
+  exchange<8, 8>(X, z, x, true, true,
+                 [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; },
+                 [&](int k) { return (((k0 * 4 + (k >> 1)) * 8 + e2) * 8 + e3) * 4 + 2 * chi + (k & 1); });
+  {
+    const uint32_t rr = 8 * e2 + e3;
+    x[0] = {gf::fold(x[0].a), gf::fold(x[0].b)}; x[1] = {gf::fold(x[1].a), gf::fold(x[1].b)};
+#pragma unroll
+    for (int k1 = 1; k1 < 4; ++k1) {
+      const uint32_t e = 5 * k1 * rr;
+      const uint64_t w = UT[e ? kM1 - e : 0];
+      x[2 * k1] = v2::p2_mul(x[2 * k1], w); x[2 * k1 + 1] = v2::p2_mul(x[2 * k1 + 1], w);
+    }
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      v2::dft4<true>(x[cl].a, x[2 + cl].a, x[4 + cl].a, x[6 + cl].a);
+      v2::dft4<true>(x[cl].b, x[2 + cl].b, x[4 + cl].b, x[6 + cl].b);
+    }
+  }
+  P2 y[10];
+  exchange<8, 10>(X, x, y, true, t < 512,
+                  [&](int k) { return (k0 * 256 + 64 * (k >> 1) + 8 * e2 + e3) * 4 + 2 * chi + (k & 1); },
+                  [&](int k) { const uint32_t g = t + 512 * (k / 5); return ((k % 5) * 256 + (g >> 2)) * 4 + (g & 3); });
+  if (t < 512) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t r = (t + 512 * q) >> 2;
+      P2 w5[5] = {y[5 * q], y[5 * q + 1], y[5 * q + 2], y[5 * q + 3], y[5 * q + 4]};
+#pragma unroll
+      for (int k0i = 1; k0i < 5; ++k0i) { const uint32_t e = r * k0i; w5[k0i] = v2::p2_mul(w5[k0i], UT[e ? kM1 - e : 0]); }
+      dft5p(w5, pl.W5c, true);
+#pragma unroll
+      for (int d0 = 0; d0 < 5; ++d0) y[5 * q + d0] = w5[d0];
+    }
+  }
+  exchange<10, 8>(X, y, x, t < 512, true,
+                  [&](int k) { const uint32_t g = t + 512 * (k / 5); return (256 * (k % 5) + (g >> 2)) * 4 + (g & 3); },
+                  [&](int k) { return (t + kThreads * (k >> 2)) * 4 + (k & 3); });
+  // ---- unweight, x a, carry along the thread's two runs ----
+  const uint32_t di = pl.DI[size_t(T) * kThreads + t];
+#pragma unroll
+  for (int d1 = 0; d1 < 2; ++d1) {
+    const uint32_t i1 = t + kThreads * d1;
+    const uint64_t tai_e = pl.TAi[i1], tai_o = pl.TAi[kM1 + i1];
+    const uint64_t tai2_e = gf::dbl(tai_e), tai2_o = gf::dbl(tai_o);
+    uint32_t ad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (EXT && ext.add_digits) {
+      const uint4* src = reinterpret_cast<const uint4*>(ext.add_digits) + (size_t(T) * kM1 + i1) * 2;
+      const uint4 v0 = src[0], v1 = src[1];
+      ad[0] = v0.x; ad[1] = v0.y; ad[2] = v0.z; ad[3] = v0.w; ad[4] = v1.x; ad[5] = v1.y; ad[6] = v1.z; ad[7] = v1.w;
+      if (ext.add_cbuf) v2::apply_carry_in<8>(pl, di, d1, v2::carry_in_of(pl, ext.add_cbuf, T, i1), ad);
+    }
+    uint64_t carry = 0;
+    uint32_t dg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t bits = di >> (2 * (d1 * 8 + k));
+      const uint32_t width = pl.q + (bits & 1u);
+      const bool wrap = (bits & 2u) != 0;
+      const P2 v = x[4 * d1 + (k >> 1)];
+      const uint64_t u = (k & 1) ? gf::mul(v.b, wrap ? tai2_o : tai_o) : gf::mul(v.a, wrap ? tai2_e : tai_e);
+      const uint64_t mask = (uint64_t(1) << width) - 1;
+      if (a == 1) {
+        const uint64_t r = u + carry + (EXT ? ad[k] : 0u);
+        dg[k] = __builtin_amdgcn_ubfe(uint32_t(r), 0u, width);
+        carry = r >> width;
+      } else {
+        const uint64_t dlo = u & mask, chi2 = u >> width;
+        const uint64_t r = dlo * a + carry + (EXT ? ad[k] : 0u);
+        dg[k] = uint32_t(r & mask);
+        carry = (r >> width) + chi2 * a;
+      }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(digits) + (size_t(T) * kM1 + i1) * 2;
+    dst[0] = make_uint4(dg[0], dg[1], dg[2], dg[3]); dst[1] = make_uint4(dg[4], dg[5], dg[6], dg[7]);
+    cbuf[size_t(T) * kM1 + i1] = carry;
+    if (EXT && ext.digits2) {
+      uint4* d2 = reinterpret_cast<uint4*>(ext.digits2) + (size_t(T) * kM1 + i1) * 2;
+      d2[0] = make_uint4(dg[0], dg[1], dg[2], dg[3]); d2[1] = make_uint4(dg[4], dg[5], dg[6], dg[7]);
+      ext.cbuf2[size_t(T) * kM1 + i1] = carry;
+    }
+  }
+  PROBE_END(pl)
+}
+
+// chain starts omega_m^(i2 (k0 + 5 k1 + 20 k2)) TB[2 i2] and ratios omega_m^(160 i2) of the B3 thread map (and inverses with TBi)
+__global__ void __launch_bounds__(640) k_build_f0(DevPlan pl, uint64_t* __restrict__ f0f, uint64_t* __restrict__ f0i, uint64_t* __restrict__ fbf, uint64_t* __restrict__ fbi) {
+  const uint32_t t = threadIdx.x, T = blockIdx.x;
+  const uint32_t c = t & 3, g2 = (t >> 2) & 7, f1 = (t >> 5) & 3, f0 = t >> 7, i2 = 4 * T + c;
+  const uint64_t ea = uint64_t(i2) * (f0 + 5 * f1 + 20 * g2);
+  f0f[size_t(T) * kThreads + t] = gf::mul(v2::tw_lookup(pl, ea), pl.TB[2 * i2]);
+  f0i[size_t(T) * kThreads + t] = gf::mul(v2::tw_lookup(pl, ea ? pl.m - ea : 0), pl.TBi[2 * i2]);
+  if (t < 4) {
+    const uint64_t eb = uint64_t(i2) * 160;
+    fbf[i2] = v2::tw_lookup(pl, eb);
+    fbi[i2] = v2::tw_lookup(pl, eb ? pl.m - eb : 0);
+  }
+}
+}  // namespace v5
+
+size_t v5_threads_per_tile() { return v5::kThreads; }
+hipError_t v5_configure() {
+  for (const void* f : {reinterpret_cast<const void*>(v5::k1_cols5), reinterpret_cast<const void*>(v5::k3_cols5<false>), reinterpret_cast<const void*>(v5::k3_cols5<true>)}) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(v5::kLdsBytes));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+hipError_t v5_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, uint64_t* fbf, uint64_t* fbi, hipStream_t s) {
+  hipLaunchKernelGGL(v5::k_build_f0, dim3(pl.M2 / pl.C), dim3(v5::kThreads), 0, s, pl, f0f, f0i, fbf, fbi);
+  return hipGetLastError();
+}
+hipError_t v5_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
+  hipLaunchKernelGGL(v5::k1_cols5, dim3(pl.M2 / pl.C), dim3(v5::kLaunchThreads), v5::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
+  return hipGetLastError();
+}
+hipError_t v5_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s) {
+  hipLaunchKernelGGL(v5::k3_cols5<false>, dim3(pl.M2 / pl.C), dim3(v5::kLaunchThreads), v5::kLdsBytes, s, pl, W, digits, cbuf, a, scale, BackExt());
+  return hipGetLastError();
+}
+hipError_t v5_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s) {
+  hipLaunchKernelGGL(v5::k3_cols5<true>, dim3(pl.M2 / pl.C), dim3(v5::kLaunchThreads), v5::kLdsBytes, s, pl, W, digits, cbuf, a, uint64_t(1), x);
+  return hipGetLastError();
+}
+#if defined(MI355_PROBE)
+hipError_t v5_probe_launch(const DevPlan& pl, int kind, int grid_mult, int extra_lds, const uint32_t* digits, uint64_t* cbuf, uint64_t* W, uint32_t* dout, hipStream_t s) {
+  const dim3 g5((pl.M2 / pl.C) * grid_mult), b5(v5::kLaunchThreads);
+  const size_t l5 = v5::kLdsBytes + size_t(extra_lds);
+  const void* f = kind == 0 ? reinterpret_cast<const void*>(v5::k1_cols5) : reinterpret_cast<const void*>(v5::k3_cols5<false>);
+  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(l5));
+  if (e != hipSuccess) return e;
+  if (kind == 0) hipLaunchKernelGGL(v5::k1_cols5, g5, b5, l5, s, pl, digits, cbuf, 0u, W);
+  else hipLaunchKernelGGL(v5::k3_cols5<false>, g5, b5, l5, s, pl, W, dout, cbuf, 1u, uint64_t(1), BackExt());
+  return hipGetLastError();
+}
+#endif
+
+}  // namespace mi355

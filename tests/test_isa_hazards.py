@@ -32,11 +32,24 @@ def test_checker_sees_a_planted_hazard_and_accepts_padded_code(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["prmers_amd/csrc/kernels_v2.hip", "prmers_amd/csrc/kernels.hip", "prmers_amd/csrc/selftest.hip"])
+@pytest.mark.parametrize("src", ["prmers_amd/csrc/kernels_v2.hip", "prmers_amd/csrc/kernels_v5.hip", "prmers_amd/csrc/kernels.hip", "prmers_amd/csrc/selftest.hip"])
 def test_shipped_kernels_have_no_unpadded_sgpr_hazard(src):
+    extra = _v2_flags() if src.endswith("kernels_v2.hip") else ()
     with tempfile.TemporaryDirectory() as td:
-        out = subprocess.run([sys.executable, CHECK, _isa(os.path.join(ROOT, src), td)], capture_output=True, text=True)
+        out = subprocess.run([sys.executable, CHECK, _isa(os.path.join(ROOT, src), td, extra)], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout[-2000:]
+
+
+def _v2_flags():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_model
+    return tuple(valu_model.V2_FLAGS)
+
+
+def test_the_model_and_the_hazard_scan_use_the_flags_of_the_makefile():
+    """kernels_v2.hip is built with its own scheduler strategy (Makefile V2FLAGS); the ISA walks must look at the same code"""
+    mk = open(os.path.join(ROOT, "prmers_amd", "csrc", "Makefile")).read()
+    assert "V2FLAGS  = " + " ".join(_v2_flags()) in mk
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
