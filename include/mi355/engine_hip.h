@@ -56,6 +56,7 @@ class engine_hip final : public engine {
     int (*mul_add)(void*, size_t, size_t, size_t, uint32_t) = nullptr;
     int (*square_mul_copy)(void*, size_t, size_t, uint32_t) = nullptr;
     int (*mul_copy)(void*, size_t, size_t, size_t, uint32_t) = nullptr;
+    int (*square_mul_n)(void*, size_t, uint32_t, size_t, uint32_t) = nullptr;   // optional (libraries before round 3 lack it)
 
     template <class F> void bind(F& f, const char* name) {
       f = reinterpret_cast<F>(dlsym(so, name));
@@ -87,6 +88,7 @@ class engine_hip final : public engine {
       bind(get_checkpoint, "mi355_engine_get_checkpoint"); bind(set_checkpoint, "mi355_engine_set_checkpoint");
       bind(addsub, "mi355_engine_addsub"); bind(addsub_copy, "mi355_engine_addsub_copy"); bind(mul_add, "mi355_engine_mul_add");
       bind(square_mul_copy, "mi355_engine_square_mul_copy"); bind(mul_copy, "mi355_engine_mul_copy");
+      square_mul_n = reinterpret_cast<decltype(square_mul_n)>(dlsym(so, "mi355_engine_square_mul_n"));
     }
     ~Api() { if (so) dlclose(so); }
   };
@@ -128,6 +130,12 @@ class engine_hip final : public engine {
   void sub(const Reg src, const uint32_t a) const override { ok(_api.sub_u32(_h, src, a), "sub"); }
   void add(const Reg dst, const Reg src) const override { ok(_api.add(_h, dst, src), "add"); }
   void sub_reg(const Reg dst, const Reg src) const override { ok(_api.sub_reg(_h, dst, src), "sub_reg"); }
+  // count x { src = src^2 * a; src -= sub }: the run of plain iterations of the callers' loops (RunPrpOrLlMarin.cpp:338-409) as one call;
+  // not part of the reference's engine (a non-virtual extra of this adapter), the loop of calls when the library does not export it
+  void square_mul_n(const Reg src, const size_t count, const uint32_t a = 1, const uint32_t sub_after = 0) const {
+    if (_api.square_mul_n) { ok(_api.square_mul_n(_h, src, a, count, sub_after), "square_mul_n"); return; }
+    for (size_t i = 0; i < count; ++i) { square_mul(src, a); if (sub_after) sub(src, sub_after); }
+  }
   // fused variants: one sweep each in the library instead of the base-class compositions (engine.h:65-131)
   void mul_add(const Reg dst, const Reg mul_src, const Reg add_src, const uint32_t a = 1) const override { ok(_api.mul_add(_h, dst, mul_src, add_src, a), "mul_add"); }
   void addsub(const Reg sum_out, const Reg diff_out, const Reg a, const Reg b) const override { ok(_api.addsub(_h, sum_out, diff_out, a, b), "addsub"); }

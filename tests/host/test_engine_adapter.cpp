@@ -43,6 +43,13 @@ int main(int argc, char** argv) {
     expect(value(*eng, 0), 3675, "square_mul");
     eng->add(0, 1); eng->sub_reg(0, 1); eng->sub(0, 2);
     expect(value(*eng, 0), 3673, "add/sub");
+    {   // the run of squarings as one call (an extra of this adapter): 5 Lucas-Lehmer steps from 4 mod 2^31 - 1
+      engine_hip* h = static_cast<engine_hip*>(eng.get());
+      eng->set(7, 4);
+      h->square_mul_n(7, 5, 1, 2);
+      uint64_t s = 4; for (int i = 0; i < 5; ++i) s = (s * s + ((uint64_t(1) << 31) - 1) - 2) % ((uint64_t(1) << 31) - 1);
+      expect(value(*eng, 7), s, "square_mul_n");
+    }
   } catch (const std::exception& ex) {
     std::printf("FAIL %s\n", ex.what());
     return 1;
