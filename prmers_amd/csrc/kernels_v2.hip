@@ -447,9 +447,10 @@ __global__ void __launch_bounds__(512, 4) k1_cols(DevPlan pl, const uint32_t* __
   P2* X = reinterpret_cast<P2*>(smem_v2);
   const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   // tile order: with two pairs per run (R = 4) four tiles share each 128-byte line of the work buffer, and keeping
-  // them on one XCD lets its L2 merge the 32-byte pieces (n = 2^24: front sweep 97 -> 89 us); with wider runs the
-  // plain order is as good or better (C3: 43.2 vs 44.9 us)
-  const uint32_t T = (R == 4) ? tile_of_block(pl, PROBE_BLOCK(pl), PROBE_GRID(pl)) : PROBE_BLOCK(pl);
+  // them on one XCD lets its L2 merge the 32-byte pieces (n = 2^24: front sweep 97 -> 89 us); with runs of eight pairs (R = 1) the
+  // XCD-contiguous order wins too (n = 2^22: 20.3 -> 19.0 us), with four (R = 2) the plain order does (C3: 34.5 vs 35.4 us; round 3,
+  // same-box A/B with MI355_TUNE bit 5, which forces the XCD-contiguous order; profiles/r03_microbench_pitch.txt has the bare patterns)
+  const uint32_t T = (R != 2 || (pl.tune & 32)) ? tile_of_block(pl, PROBE_BLOCK(pl), PROBE_GRID(pl)) : PROBE_BLOCK(pl);
   boost_if_late(pl.boost_tiles);
   PROBE_BEGIN(pl)
   uint32_t dg[R][16 / R];

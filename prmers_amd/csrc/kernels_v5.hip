@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const 
   using v2::P2;
   if (threadIdx.x >= kThreads) return;   // the two padding waves (kLaunchThreads): ended waves do not count at a barrier
   uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
-  const uint32_t t = threadIdx.x, T = PROBE_BLOCK(pl);
+  const uint32_t t = threadIdx.x, T = (pl.tune & 32) ? v2::tile_of_block(pl, PROBE_BLOCK(pl), PROBE_GRID(pl)) : PROBE_BLOCK(pl);   // MI355_TUNE bit 5: A/B
   v2::boost_if_late(pl.boost_tiles);
   PROBE_BEGIN(pl)
   const uint64_t* __restrict__ UT = stage_roots(pl, X);
