@@ -133,3 +133,19 @@ def test_an_injected_error_is_caught_on_the_one_launch_path():
         msgs = []
         r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, erroriter=1500, log=msgs.append)
         assert r["is_prime"] and r["gerbicz_errors"] == 1 and any("Check FAILED" in m for m in msgs)
+
+
+@pytest.mark.parametrize("p,plan", [(57885161, None), (205271257, None), (1600589, "m2=32,c=4"), (3200123, "m2=8,split5")])
+def test_runs_of_squarings_on_the_register_resident_and_split_paths(p, plan):
+    """square_mul_n where it is the loop of launches (every shape the one-launch kernel does not serve): same digits as the loop of
+    square_mul / sub calls, PRP and Lucas-Lehmer forms, pending subtraction carried across the calls"""
+    rng = np.random.default_rng(p)
+    x0 = int.from_bytes(rng.bytes(64), "little")
+    with Engine(p, 2, plan=plan) as e:
+        e.set_int(0, x0); e.set_int(1, x0)
+        e.square_mul_n(0, 6, 3)
+        for _ in range(6): e.square_mul(1, 3)
+        assert np.array_equal(e.digits(0), e.digits(1))
+        e.square_mul_n(0, 5, 1, 2); e.square_mul_n(0, 2, 1, 2)
+        for _ in range(7): e.square_mul(1); e.sub(1, 2)
+        assert np.array_equal(e.digits(0), e.digits(1)) and e.is_equal(0, 1)
