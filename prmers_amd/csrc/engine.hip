@@ -289,6 +289,7 @@ void Engine::write_values(size_t dst, const std::vector<uint32_t>& natural) {
 uint32_t* Engine::canon_digits(size_t r, int slot) {
   need_digits(r, "get");
   HIPCHK(hipSetDevice(device_));
+  coop_check();   // nothing is read out of an engine whose one-launch kernel gave up at a grid barrier
   const size_t sw = canon_scratch_words(dp_);
   if (!canon_) {
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&canon_), (sw + 2 * pl_.n) * 4));
@@ -328,6 +329,7 @@ void Engine::read_values_host(size_t src, std::vector<uint64_t>& v) {
   need_digits(src, "get");
   stage_.resize(pl_.n);
   HIPCHK(hipSetDevice(device_));
+  coop_check();
   normalize(src);
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(stage_.data(), digits(src), pl_.n * 4, hipMemcpyDeviceToHost));
@@ -697,6 +699,7 @@ void Engine::get_data(size_t src, void* data, size_t size) {
   check_reg(src);
   if (size != register_data_size()) throw std::runtime_error("get_data: size mismatch");
   HIPCHK(hipSetDevice(device_));
+  coop_check();
   normalize(src);
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(data, slot_[src], reg_bytes_, hipMemcpyDeviceToHost));
