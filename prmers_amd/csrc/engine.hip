@@ -131,6 +131,8 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     if (coop_groups_) {
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&coop_flags_), (size_t(coop_groups_) + 64) * 4));
       HIPCHK(hipMemsetAsync(coop_flags_, 0, (size_t(coop_groups_) + 64) * 4, stream_));
+      const char* cf = std::getenv("MI355_COOP_FAULT");   // test hook: work-group 0 skips its barriers (tests/test_gpu_coop.py)
+      coop_fault_ = (cf && cf[0] == '1') ? 1u : 0u;
       const char* cb = std::getenv("MI355_COOP_BATCH");
       if (cb && std::atoi(cb) > 1) coop_batch_ = size_t(std::atoi(cb));
     }
@@ -192,7 +194,7 @@ void Engine::coop_launch(size_t r, uint32_t a, size_t count, uint32_t sub_next) 
   while (count) {
     const uint32_t c = uint32_t(std::min<size_t>(count, 1u << 20));
     HIPCHK(launch_coop(dp_, coop_groups_, digits(r), cbuf(r), pending_carry_[r] != 0, work(), a, pending_sub_[r], sub_next, c, coop_flags_,
-                       coop_flags_ + coop_groups_, coop_epoch_, stream_));
+                       coop_flags_ + coop_groups_, coop_epoch_, coop_fault_, stream_));
     coop_epoch_ += 3 * c - 1;
     pending_carry_[r] = 1;
     pending_sub_[r] = sub_next;

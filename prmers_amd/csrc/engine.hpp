@@ -124,7 +124,7 @@ class Engine {
   bool host_carry_ = false;      // MI355_HOST_CARRY=1: compare / res64 / read-back through the host (A/B tests)
   // one-launch squarings of the small transforms (kernels.hip k_coop): grid size (0: not served / MI355_COOP=0), barrier words
   // [groups] + error word, barriers passed so far, squarings per launch in time_square_mul (MI355_COOP_BATCH, A/B and bench)
-  uint32_t coop_groups_ = 0, coop_epoch_ = 0;
+  uint32_t coop_groups_ = 0, coop_epoch_ = 0, coop_fault_ = 0;
   uint32_t* coop_flags_ = nullptr;
   size_t coop_batch_ = 1;
   bool coop_used_ = false, coop_failed_ = false;

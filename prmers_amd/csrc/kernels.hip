@@ -545,6 +545,7 @@ struct CoopArgs {
   uint32_t* flags; uint32_t* err;                     // barrier words (one per work-group), error word
   uint32_t a, sub, count, epoch0, carry_in;           // x <- (x^2 - sub?) ... : every squaring is square_mul(a) preceded by the pending "- sub"
   uint32_t sub_next;                                  // subtraction folded into the front sweeps of squarings 2 .. count (Lucas-Lehmer runs)
+  uint32_t fault;                                     // test hook (MI355_COOP_FAULT=1): work-group 0 leaves before its first barrier
 };
 
 __global__ void __launch_bounds__(1024) k_coop(DevPlan pl, CoopArgs ca) {
@@ -552,6 +553,7 @@ __global__ void __launch_bounds__(1024) k_coop(DevPlan pl, CoopArgs ca) {
   const uint32_t tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x, G = gridDim.x;
   const uint32_t NT = pl.M2 / pl.C, M1 = pl.M1;
   uint32_t epoch = ca.epoch0;
+  if (ca.fault && b == 0) return;   // the others must notice at their barrier, raise the error word and drain (tests/test_gpu_coop.py)
   for (uint32_t it = 0; it < ca.count; ++it) {
     const uint64_t* cin = (it || ca.carry_in) ? ca.cbuf : nullptr;
     const uint32_t sub = it ? ca.sub_next : ca.sub;
@@ -879,9 +881,9 @@ uint32_t coop_groups(const DevPlan& pl, int device) {
   return want <= room ? want : 0;   // a grid smaller than the tile count would serialise tiles inside a group: not the case this is for
 }
 hipError_t launch_coop(const DevPlan& pl, uint32_t groups, uint32_t* digits, uint64_t* cbuf, bool carry_in, uint64_t* W, uint32_t a, uint32_t sub, uint32_t sub_next,
-                       uint32_t count, uint32_t* flags, uint32_t* err, uint32_t epoch0, hipStream_t s) {
+                       uint32_t count, uint32_t* flags, uint32_t* err, uint32_t epoch0, uint32_t fault, hipStream_t s) {
   DevPlan plc = pl;
-  CoopArgs ca{digits, cbuf, W, flags, err, a, sub, count, epoch0, carry_in ? 1u : 0u, sub_next};
+  CoopArgs ca{digits, cbuf, W, flags, err, a, sub, count, epoch0, carry_in ? 1u : 0u, sub_next, fault};
   void* args[2] = {&plc, &ca};
   return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_coop), dim3(groups), dim3(coop_threads(pl)), args, unsigned(coop_lds(pl)), s);
 }

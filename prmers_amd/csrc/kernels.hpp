@@ -54,7 +54,7 @@ uint32_t coop_groups(const DevPlan& pl, int device);
 // flags: `groups` barrier words, err: error word (both device-visible, zero at first use); epoch0: barriers passed so far on these flags
 // (each squaring passes 3, the last one of a launch 2); sub: subtracted before the first squaring, sub_next before each later one
 hipError_t launch_coop(const DevPlan& pl, uint32_t groups, uint32_t* digits, uint64_t* cbuf, bool carry_in, uint64_t* W, uint32_t a, uint32_t sub, uint32_t sub_next,
-                       uint32_t count, uint32_t* flags, uint32_t* err, uint32_t epoch0, hipStream_t s);
+                       uint32_t count, uint32_t* flags, uint32_t* err, uint32_t epoch0, uint32_t fault, hipStream_t s);   // fault: test hook, see CoopArgs
 // columns of 5 L1 pairs that do not fit LDS (n = 5 * 2^26): the radix-5 stage through a second work buffer U (8 n bytes), C = 1
 hipError_t configure_split(const DevPlan& pl);
 hipError_t launch_front_split(const DevPlan& pl, const uint32_t* digits, uint64_t* U, uint64_t* W, hipStream_t s);

@@ -149,3 +149,19 @@ def test_runs_of_squarings_on_the_register_resident_and_split_paths(p, plan):
         e.square_mul_n(0, 5, 1, 2); e.square_mul_n(0, 2, 1, 2)
         for _ in range(7): e.square_mul(1); e.sub(1, 2)
         assert np.array_equal(e.digits(0), e.digits(1)) and e.is_equal(0, 1)
+
+
+def test_a_grid_barrier_that_times_out_is_reported_and_poisons_the_engine():
+    """MI355_COOP_FAULT=1 makes work-group 0 leave before its first barrier (what a group that is not resident would look like): the other
+    groups give up after 0.2 s, raise the error word and drain; the next read-out and every later call fail with the reason."""
+    from prmers_amd.engine import EngineError
+    with env(MI355_COOP=1, MI355_COOP_FAULT=1):
+        e = Engine(9941, 2, plan="m2=16,c=4")
+        with e:
+            assert ":coop=" in e.describe()
+            e.set(0, 3)
+            e.square_mul(0)                      # asynchronous: the launch itself succeeds
+            with pytest.raises(EngineError, match="grid barrier timed out"):
+                e.digits(0)
+            with pytest.raises(EngineError, match="grid barrier timed out"):
+                e.square_mul(0)
