@@ -218,10 +218,15 @@ def main(argv=None):
 
     # rendezvous first: nothing below may touch the GPU before the process group exists
     device = "cpu"
+    ndev = max(1, torch.cuda.device_count())   # (counting devices does not initialise the GPU)
+    gpu = local_rank % ndev                    # more ranks than GPUs: rank i runs on device i mod N (two tests fill each other's launch gaps)
     if world > 1:
         if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) > ndev:
+                sys.stderr.write("error: %d ranks on %d GPU(s): RCCL takes one rank per device; use --backend gloo for the status word\n" % (world, ndev))
+                return 2
+            torch.cuda.set_device(gpu)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
             device = "cuda"
         else:
             dist.init_process_group(args.backend)
@@ -240,7 +245,7 @@ def main(argv=None):
     for sig in (signal.SIGINT, signal.SIGTERM):
         signal.signal(sig, lambda *_: stop.set())
     try:
-        results, status = run_sharded(lines, lambda p: Engine(p, prp.REGISTERS, device=local_rank, plan=args.fft), device=device, max_iters=args.max_iters,
+        results, status = run_sharded(lines, lambda p: Engine(p, prp.REGISTERS, device=gpu, plan=args.fft), device=device, max_iters=args.max_iters,
                                       checklevel=args.checklevel, log=log, per_gpu=args.per_gpu, on_status=on_status, should_stop=stop.is_set,
                                       ckpt_dir=args.ckpt_dir, backup_interval_s=args.backup_interval)
     finally:
