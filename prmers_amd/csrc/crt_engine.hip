@@ -680,7 +680,11 @@ std::string CrtEngine::describe() const {
   return "crt-hip:n=" + std::to_string(im_->g.n) + ":odd=" + std::to_string(gr.odd) + ":m=" + std::to_string(gr.m) + ":h1=" + std::to_string(1u << gr.logH1) + ":h2=" +
          std::to_string(1u << gr.logH2) + (im_->fast ? ":radix8" : ":generic");
 }
-size_t CrtEngine::algorithmic_bytes() const { return size_t(im_->g.n) * (8 + 8 + 2 * 12 + 8 * 12); }   // digits r + w, carry sweep input, 4 row passes r + w
+size_t CrtEngine::algorithmic_bytes() const {   // digits r + w, 4 row passes r + w, and (two-kernel form only) the carry sweep's input w + r
+  const crt::Grid& gr = im_->gr;
+  const bool fused = gr.odd > 1 && (gr.h & 255u) == 0 && !(gr.tune & 2u);   // k_back_carry (launch_transform)
+  return size_t(im_->g.n) * (8 + 8 + 8 * 12 + (fused ? 0 : 2 * 12));
+}
 
 void CrtEngine::sync() {
   chk(hipSetDevice(im_->device), "hipSetDevice");
