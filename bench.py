@@ -109,7 +109,7 @@ def bench_crt(args):
                         "frac": round(bytes_iter / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "traffic_source": "profiles/traffic_crt_latest.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                         "algorithmic_bytes_per_iteration": bytes_iter, "stage_ms": {k: round(v, 5) for k, v in kern.items()},
-                        "note": "whole iteration (stages are several launches each); first kernel set, see DESIGN.md section N1"}}
+                        "note": "whole iteration; stage slots: front, forward columns, rows + pointwise + inverse rows, inverse columns, back + carry (one kernel), range edges; DESIGN.md section 7 N1"}}
     print(json.dumps(out))
     eng.close()
 
