@@ -306,7 +306,7 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
         r = 1
         if batched:
             r = (j % B + 1) if (prp and gerbicz) else (total - it)
-            r = min(r, total - it)
+            r = min(r, total - it, 65536)      # (a bound on one engine call: the loop stays responsive without Gerbicz-Li boundaries)
             if erroriter > 0 and not errordone and erroriter > it:
                 r = min(r, erroriter - it)
             if max_iters is not None:
