@@ -96,7 +96,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     const char* bf = std::getenv("MI355_BOOST");           // boosted part of the last round in percent (default 50)
     const uint32_t pct = bf ? uint32_t(std::atoi(bf)) : 50u;
     auto from = [&](size_t grid) { return (!(dp_.tune & 4) && grid > slots) ? uint32_t(grid - size_t(slots) * pct / 100) : ~0u; };
-    dp_.boost_rows = from(pl_.M1);
+    dp_.boost_rows = from(pl_.M2 == 2048 ? pl_.M1 / 2 : pl_.M1);   // (rows of 2048 go two to a tile on the register-resident row kernel)
     dp_.boost_tiles = from(pl_.tiles());
   }
   HIPCHK(configure_kernels(pl_.lds_front, pl_.lds_mid));

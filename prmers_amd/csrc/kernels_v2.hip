@@ -42,22 +42,67 @@ namespace v2 {
 // h = 0 forms the sums, h = 1 the differences times omega_8192^i, each group loads both halves), then each
 // group runs the 4096-point machinery on its own LDS half (2 x 72 KiB); output index k of group h is row
 // frequency 2k + h.  The inverse ends with the mirror butterfly through LDS.
-template <int mode, int H>
+// RL = 1 serves rows of 2048 (round 3; the reference's sqr512 / forward1024 shapes, kernels/marin.cl:1190,1517): a tile is two adjacent rows,
+// the first-stage registers 4 r .. 4 r + 3 belong to row r of the tile, the first stage is a radix-4 per row (32-point blocks: seam
+// omega_32^(k1' d2), still uniform per wave), the table seam reads omega_2048^((k1' + 4 k2)(8 d3 + d4)) (plan.hpp builds S2r for this shape)
+// and everything after it is the 4096-point code with the row carried in the top bit of the k1 field: X[k], k = k1' + 4 k2 + 32 k3 + 256 k4
+// of row 2 tile + (k1 >> 2).  n = 2^21: 0.0645 -> 0.0577 ms, n = 5 2^20 (p ~ 100 M): 0.130 -> 0.120 ms (same-box A/B against the generic rows,
+// MI355_TUNE bit 6).  (Four rows of 1024 to a tile -- RL = 2, a radix-2 first stage -- were built and measured too: n = 5 2^19 has only
+// 320 such tiles for 256 CUs and lost 2.4 % against the generic rows; not kept.)
+template <int RL, int W, bool INV>
+__device__ __forceinline__ void seam_rows_const(P2 (&x)[8]) {   // x[(8 >> RL) r + k1'] *= omega_(64 >> RL)^(+-k1' W) = 2^(+-39 2^RL k1' W)
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    constexpr int R1 = 8 >> RL;
+    if ((k & (R1 - 1)) == 0) continue;
+    const unsigned f = ((1u << RL) * gf::LOG2_W64 * unsigned(k & (R1 - 1)) * unsigned(W)) % 192u;
+    const unsigned sh = INV ? (192u - f) % 192u : f;
+    x[k] = {gf::mul_pow2(x[k].a, sh), gf::mul_pow2(x[k].b, sh)};
+  }
+}
+template <int RL, bool INV>
+__device__ __forceinline__ void seam_rows(P2 (&x)[8], uint32_t wave) {
+  switch (wave) {
+    case 0: break;
+    case 1: seam_rows_const<RL, 1, INV>(x); break;
+    case 2: seam_rows_const<RL, 2, INV>(x); break;
+    case 3: seam_rows_const<RL, 3, INV>(x); break;
+    case 4: seam_rows_const<RL, 4, INV>(x); break;
+    case 5: seam_rows_const<RL, 5, INV>(x); break;
+    case 6: seam_rows_const<RL, 6, INV>(x); break;
+    default: seam_rows_const<RL, 7, INV>(x); break;
+  }
+}
+template <int RL, bool INV>
+__device__ __forceinline__ void dft_rows_first(P2 (&x)[8]) {   // the first-stage transform of every row of the tile, both planes
+  static_assert(RL == 1, "two rows to a tile");   // a radix-4 on registers 0 .. 3 and 4 .. 7
+  dft4<INV>(x[0].a, x[1].a, x[2].a, x[3].a); dft4<INV>(x[0].b, x[1].b, x[2].b, x[3].b);
+  dft4<INV>(x[4].a, x[5].a, x[6].a, x[7].a); dft4<INV>(x[4].b, x[5].b, x[6].b, x[7].b);
+}
+
+template <int mode, int H, int RL = 0>
 __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
                                                           uint64_t* __restrict__ Wout, uint32_t sub) {
+  static_assert(RL == 0 || (RL == 1 && H == 1), "two rows to a tile only with one tile per work-group");
+  constexpr bool HALF = (RL > 0);
+  constexpr int HH = H;                 // 4096-pair tiles per work-group
+  constexpr int R1 = 8 >> RL;           // first-stage radix
   const uint32_t h = (H == 2) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0u;
   if (H == 1) boost_if_late(pl.boost_rows);
   P2* X = reinterpret_cast<P2*>(smem_v2) + h * kLdsSlots;
-  const uint32_t t = threadIdx.x & 511, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7), row = PROBE_BLOCK(pl);
+  const uint32_t t = threadIdx.x & 511, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7);
+  const uint32_t tile = PROBE_BLOCK(pl);
+  const uint32_t row = HALF ? (tile << RL) + (lane >> (6 - RL)) : tile;    // several rows: the row this thread's S4 outputs (and pointwise words) belong to
   PROBE_BEGIN(pl)
-  const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * (4096 * H);
-  P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * (4096 * H) + h * 4096;
+  const P2* in = reinterpret_cast<const P2*>(Win) + size_t(tile) * (4096 * HH);
+  P2* out = reinterpret_cast<P2*>(Wout) + size_t(tile) * (4096 * HH) + h * 4096;
   P2 x[8];
   // table words of the pointwise stage, requested first: their latency hides behind the forward transform
-  const uint32_t kb = (lane >> 3) + 8 * (lane & 7) + 64 * wave;   // S4 thread (k3|k1|k2): frequency base k1 + 8 k2 + 64 k3
+  // S4 thread (k3|k1|k2): frequency base k1 + 8 k2 + 64 k3 (several rows: k1' + R1 k2 + 8 R1 k3 with k1' = k1 & (R1 - 1))
+  const uint32_t kb = ((lane >> 3) & uint32_t(R1 - 1)) + R1 * (lane & 7) + 8 * R1 * wave;
   const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;       // column-DFT slot -> frequency (kernels.hip freq1)
   const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
-  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * (H * kb + h);   // row frequency of X[kb]: H kb + h
+  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * (HH * kb + h);   // row frequency of X[kb]: H kb + h
   const uint64_t rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)], rho_hi = pl.TWhi[erho >> pl.twh];
 
   // ---- forward ----
@@ -66,7 +111,10 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   if (H == 1) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = in[512 * j + t];
-    if (sub != 0 && t == 0) x[0].a = gf::sub(x[0].a, uint64_t(sub));
+    if (sub != 0 && t == 0) {
+#pragma unroll
+      for (int r = 0; r < (1 << RL); ++r) x[R1 * r].a = gf::sub(x[R1 * r].a, uint64_t(sub));   // element 0 of every row of the tile
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -77,8 +125,11 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
       else x[j] = p2_mul(P2{gf::sub(lo.a, hi.a), gf::sub(lo.b, hi.b)}, pl.UT2[512 * j + t]);
     }
   }
-  dft8p<false, 1>(x);   // outputs 1..7 are shifted next, output 0 is not
-  seam64<false, true>(x, wave);
+  if constexpr (HALF) { dft_rows_first<RL, false>(x); seam_rows<RL, false>(x, wave); }
+  else {
+    dft8p<false, 1>(x);   // outputs 1..7 are shifted next, output 0 is not
+    seam64<false, true>(x, wave);
+  }
   uint64_t sw[8];   // seam twiddles: loaded before the exchange so that their latency hides behind it
   {
     const uint32_t k1 = t & 7, b = t >> 3;
@@ -111,7 +162,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   // ---- pointwise: reg k4 holds X[kb + 512 k4]; rho = omega_m^(k1row + M1 k) = rho0 * omega_8^k4 ----
   {
     const uint64_t rho0 = gf::mul(rho_lo, rho_hi);
-    const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * (4096 * H) + h * 4096;
+    const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(tile) * (4096 * HH) + h * 4096;
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       // omega_8^k4 = 2^(120 k4): +1, -2^24, +2^48, -2^72, -1, +2^24, -2^48, +2^72
@@ -157,9 +208,12 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   for (int k2 = 0; k2 < 8; ++k2) x[k2] = p2_mul(x[k2], sw[k2]);
   dft8p<true>(x);
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
-  seam64<true>(x, wave);
-  if (H == 1) dft8p<true, 2>(x);   // stored for a back sweep, which multiplies by its twiddle first
-  else dft8p<true>(x);
+  if constexpr (HALF) { seam_rows<RL, true>(x, wave); dft_rows_first<RL, true>(x); }
+  else {
+    seam64<true>(x, wave);
+    if (H == 1) dft8p<true, 2>(x);   // stored for a back sweep, which multiplies by its twiddle first
+    else dft8p<true>(x);
+  }
   if (H == 2) {   // mirror of the top radix-2 level: lo = A + B w^-i, hi = A - B w^-i (A from group 0, B from group 1)
     if (h == 1) {
 #pragma unroll
@@ -557,7 +611,13 @@ hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 
 // ------------------------------- launch wrappers ---------------------------------------------
 
-bool v2_rows_supported(const DevPlan& pl) { return (pl.M2 == 4096 || pl.M2 == 8192) && pl.S2r != nullptr; }
+// rows of 2048 go two to a tile: only where that still gives at least one work-group per CU (n = 2^21, 5 2^20); below that the generic
+// rows win.  MI355_TUNE bit 6 switches them off (A/B runs)
+bool v2_rows_supported(const DevPlan& pl) {
+  if (pl.S2r == nullptr) return false;
+  if (pl.M2 == 4096 || pl.M2 == 8192) return true;
+  return pl.M2 == 2048 && pl.M1 % 2 == 0 && pl.M1 >= 512 && !(pl.tune & 64);
+}
 // columns: M1 = 512 R, R in {1, 2, 4}, with C = 8 / R pairs per run (one 4096-pair tile per work-group)
 bool v2_cols_supported(const DevPlan& pl) {
   if (v5_cols_shape(pl)) return pl.DI != nullptr;
@@ -571,6 +631,7 @@ bool v2_cols_supported(const DevPlan& pl) {
 hipError_t v2_configure() {
   MI355_SET_LDS((v2::k2_rows4096<0, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 1>), v2::kLdsBytes)
   MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes)
+  MI355_SET_LDS((v2::k2_rows4096<0, 1, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 1, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 1, 1>), v2::kLdsBytes)
   MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
   { hipError_t e5 = v5_configure(); if (e5 != hipSuccess) return e5; }
@@ -580,7 +641,11 @@ hipError_t v2_configure() {
 #undef MI355_SET_LDS
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
 #define MI355_ROWS(MODE, HH) hipLaunchKernelGGL((v2::k2_rows4096<MODE, HH>), dim3(pl.M1), dim3(512 * HH), HH * v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
-  if (pl.M2 == 4096) {   // one instantiation per mode: the squaring kernel carries no multiply / image code
+  if (pl.M2 == 2048) {   // two rows to a tile
+#define MI355_ROWS_TWO(MODE) hipLaunchKernelGGL((v2::k2_rows4096<MODE, 1, 1>), dim3(pl.M1 / 2), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
+    switch (mode) { case 0: MI355_ROWS_TWO(0); break; case 1: MI355_ROWS_TWO(1); break; default: MI355_ROWS_TWO(2); break; }
+#undef MI355_ROWS_TWO
+  } else if (pl.M2 == 4096) {   // one instantiation per mode: the squaring kernel carries no multiply / image code
     switch (mode) { case 0: MI355_ROWS(0, 1); break; case 1: MI355_ROWS(1, 1); break; default: MI355_ROWS(2, 1); break; }
   } else {
     switch (mode) { case 0: MI355_ROWS(0, 2); break; case 1: MI355_ROWS(1, 2); break; default: MI355_ROWS(2, 2); break; }

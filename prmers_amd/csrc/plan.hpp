@@ -215,6 +215,13 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
       pl.S2r[idx] = pl.UT2[st * e]; pl.S2ri[idx] = pl.UT2[st * ((4096 - e) & 4095)];
     }
   }
+  if (pl.M2 == 2048) {   // rows of 2048 two to a tile (kernels_v2.hip, RL = 1): [b][k1][k2] with k1 = 4 row + k1', omega_2048^((k1' + 4 k2) b)
+    pl.S2r.resize(4096); pl.S2ri.resize(4096);
+    for (uint32_t b = 0; b < 64; ++b) for (uint32_t k1 = 0; k1 < 8; ++k1) for (uint32_t k2 = 0; k2 < 8; ++k2) {
+      const uint32_t e = (((k1 & 3) + 4 * k2) * b) & 2047;
+      pl.S2r[b * 64 + k1 * 8 + k2] = pl.UT2[e]; pl.S2ri[b * 64 + k1 * 8 + k2] = pl.UT2[(2048 - e) & 2047];
+    }
+  }
   if (pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048)) {   // M1 = 512 R = (8R) x 64
     const uint32_t ka_n = pl.M1 / 64;
     pl.S1r.resize(pl.M1); pl.S1ri.resize(pl.M1);

@@ -269,6 +269,38 @@ def test_c3_136279841_full_size():
         assert e.res64(0) == o.res64(0)
 
 
+@pytest.mark.parametrize("p,plan,shape", [(30402457, None, "m1=512:m2=2048:c=8"), (30402457, "m2=2048,c=4", "m1=512:m2=2048:c=4"),
+                                          (100000007, None, "m1=1280:m2=2048:c=4"), (38000009, "m2=2048,c=2", "m1=512:m2=2048:c=2")])
+def test_rows_of_2048_two_to_a_tile(p, plan, shape, monkeypatch):
+    """rows of 2048 on the register-resident row kernel (kernels_v2.hip, RL = 1: two rows per 4096-pair tile; the reference's
+    forward1024 / sqr512 shapes, kernels/marin.cl:1190,1517): n = 2^21 with register-resident and with generic columns, n = 5 2^20
+    (p ~ 100 M) with the radix-5 columns -- squarings, x a, the LL step (subtraction folded into the next sweep), multiplicand and mul
+    against the oracle's digits, and against the generic rows (MI355_TUNE bit 6) on the same inputs."""
+    o = orc.Oracle(p, 3)
+    rng = np.random.default_rng(p)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 4, plan=plan) as e:
+        assert shape in e.describe(), e.describe()
+        monkeypatch.setenv("MI355_TUNE", "64")
+        with Engine(p, 4, plan=plan) as g:
+            e.set_digits(0, d0); g.set_digits(0, d0); o.set_digits(0, d0)
+            for it in range(3):
+                e.square_mul(0); g.square_mul(0); o.square_mul(0)
+            assert np.array_equal(e.digits(0), o.digits(0)) and np.array_equal(g.digits(0), o.digits(0))
+            e.square_mul(0, 3); o.square_mul(0, 3)
+            e.sub(0, 2); o.sub(0, 2)
+            e.square_mul(0); o.square_mul(0)
+            assert np.array_equal(e.digits(0), o.digits(0))
+            e.copy(1, 0); o.copy(1, 0)
+            e.square_mul(1); o.square_mul(1)
+            e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)
+            e.mul(0, 2, 3); o.mul(0, 2, 3)
+            e.square_mul(0); o.square_mul(0)
+            assert np.array_equal(e.digits(0), o.digits(0))
+            assert e.res64(0) == o.res64(0)
+
+
 def test_full_size_properties_no_oracle():
     """size-independent identities at n = 2^23: (x*y)^2 == x^2 * y^2 and (x+y)^2 - x^2 - y^2 == 2xy."""
     p = 136279841
