@@ -13,8 +13,10 @@ region.  Rank 0 prints ONE JSON line.  Extra objects:
                   measured cost of an event record: agrees with rocprofv3 --kernel-trace), against the
                   8 TB/s HBM peak
   roofline.valu -- the binding roof as a number: VALU instructions and issue cycles per wave of each kernel from the ISA walk
-                  (tools/valu_model.py -> profiles/valu_model_latest.json), predicted_us = waves per SIMD x cycles / 2.4 GHz,
-                  frac = predicted / measured per kernel and for the squaring
+                  (tools/valu_model.py -> profiles/valu_model_latest.json: instruction counts of the built kernels, no timing in it),
+                  predicted_us = waves per SIMD x cycles / the shader clock READ DURING THIS RUN (hwmon sclk sampled while a
+                  batch of squarings runs), frac = predicted / measured per kernel and for the squaring; without a readable
+                  clock the time prediction is left out (cycles only)
   preheat      -- untimed squarings before --warmup until the GPU clock has ramped (a cold box runs the
                   first tens of milliseconds slower; --steps/--warmup keep their meaning)
   cpu_baseline -- the CPU oracle (a port of the reference's algorithm; the reference has no CPU
@@ -45,6 +47,68 @@ def seeded_digits(p, n, seed):
     rng = np.random.default_rng(seed)
     d = rng.integers(0, 1 << 62, n, dtype=np.uint64) & ((np.uint64(1) << width) - np.uint64(1))
     return d | (width << np.uint64(32))
+
+
+def _sclk_files(device_index):
+    """hwmon frequency inputs labelled sclk of the GPU behind HIP device `device_index` (one per XCD on multi-die parts)."""
+    import glob
+    import torch
+    roots = []
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        roots = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+    except Exception:
+        roots = []
+    if not roots:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        roots = cards[device_index:device_index + 1] if len(cards) > device_index else cards[:1]
+    files = []
+    for r in roots:
+        for lab in sorted(glob.glob(os.path.join(r, "freq*_label"))):
+            try:
+                if open(lab).read().strip() == "sclk":
+                    files.append(lab.replace("_label", "_input"))
+            except OSError:
+                pass
+    return files
+
+
+def measure_shader_clock(eng, device_index, iters=3000):
+    """Shader clock (GHz) under THIS workload: the hwmon sclk inputs sampled from a second thread while `iters` squarings run
+    (the ctypes call releases the GIL).  -> (GHz or None, description of the source)."""
+    import threading
+    files = _sclk_files(device_index)
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            vals = []
+            for f in files:
+                try:
+                    vals.append(float(open(f).read().strip()))   # Hz
+                except (OSError, ValueError):
+                    pass
+            if vals:
+                samples.append(sum(vals) / len(vals))
+            time.sleep(0.005)
+    if files:
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        eng.time_square_mul(0, iters)
+        stop.set(); th.join()
+        busy = [v for v in samples[len(samples) // 4:] if v > 0]   # (the first quarter may still see the idle clock)
+        if busy:
+            return sum(busy) / len(busy) / 1e9, "hwmon sclk, %d samples over %d squarings, %d sensor(s)" % (len(busy), iters, len(files))
+    try:   # amdsmi through torch, sampled right after a batch (coarser: one reading)
+        import torch
+        eng.time_square_mul(0, iters // 4)
+        mhz = float(torch.cuda.clock_rate(device_index))
+        if mhz > 0:
+            return mhz / 1e3, "torch.cuda.clock_rate after a batch of squarings"
+    except Exception:
+        pass
+    return None, "no readable shader clock on this box (hwmon sclk and torch.cuda.clock_rate both unavailable)"
 
 
 def cpu_baseline(p, sample_iters=100):
@@ -245,26 +309,30 @@ def main():
         except Exception:
             traffic = None
         valu = None
-        try:   # the VALU issue model of the three kernels (ISA walk, tools/valu_model.py) against this run's kernel times
+        try:   # the VALU issue model of the three kernels (ISA walk, tools/valu_model.py) against this run's kernel times and clock
             vm = json.load(open(os.path.join(ROOT, "profiles", "valu_model_latest.json")))
             if vm.get("plan") == __import__("prmers_amd").resolve_plan(p, args.plan):
+                ghz, clock_source = measure_shader_clock(eng, local_rank)
+                simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+                waves_per_simd = vm["waves_per_launch"] / simds
                 ks = {}
                 for k, v in vm["kernels"].items():
                     if k in chain:
+                        pred = waves_per_simd * v["issue_cycles_per_wave"] / (ghz * 1e3) if ghz else None
                         ks[k] = {"insts": int(round(v["valu_insts_per_wave"] * vm["waves_per_launch"])), "issue_cycles_per_wave": v["issue_cycles_per_wave"],
-                                 "predicted_us": v["predicted_us"], "measured_us": round(chain[k] * 1e3, 2),
-                                 "frac": round(v["predicted_us"] / (chain[k] * 1e3), 4)}
-                pred = sum(v["predicted_us"] for v in ks.values())
+                                 "predicted_us": round(pred, 2) if pred else None, "measured_us": round(chain[k] * 1e3, 2),
+                                 "frac": round(pred / (chain[k] * 1e3), 4) if pred else None}
+                pred = sum(v["predicted_us"] for v in ks.values()) if ghz else None
                 valu = {"insts": sum(v["insts"] for v in ks.values()), "issue_cycles": round(sum(v["issue_cycles_per_wave"] for v in ks.values()), 1),
-                        "predicted_us": round(pred, 2), "measured_us": round(ms_per_step * 1e3, 2), "frac": round(pred / (ms_per_step * 1e3), 4),
-                        "clock_ghz_assumed": vm["clock_ghz"], "kernels": ks,
-                        "steady_state_frac": {"k_front": 0.95, "k_middle": 1.0, "k_back": 0.99},
-                        "note": "frac = predicted VALU issue time / measured time.  steady_state_frac: the same against the marginal cost of 1024 more tiles in "
-                                "one launch (profiles/r03_probe_timeline.md): the kernels sit on the VALU roof, the rest is a fixed cost per launch "
-                                "(launch-to-launch gap, unequal XCD clocks, entry loads and single-group tails)",
-                        "source": "profiles/valu_model_latest.json (tools/valu_model.py)"}
-        except Exception:
-            valu = None
+                        "predicted_us": round(pred, 2) if pred else None, "measured_us": round(ms_per_step * 1e3, 2),
+                        "frac": round(pred / (ms_per_step * 1e3), 4) if pred else None,
+                        "shader_clock_ghz": round(ghz, 4) if ghz else None, "shader_clock_source": clock_source, "simds": simds, "kernels": ks,
+                        "note": "frac = predicted VALU issue time (instruction walk of the built kernels x measured issue cost per opcode, at the shader "
+                                "clock read during this run) / measured time; the marginal-cost probe behind the steady-state figures is "
+                                "profiles/r03_probe_timeline.md (a separate -DMI355_PROBE build, not part of this run)",
+                        "source": "profiles/valu_model_latest.json (tools/valu_model.py) + this run's kernel times and clock"}
+        except Exception as exc:
+            valu = {"error": "valu model unavailable: %s" % exc}
         out = {
             "metric": "PRP squaring throughput at p~136M (Marin IBDWT, one exponent per GPU)",
             "value": round(world * args.steps / elapsed, 3),

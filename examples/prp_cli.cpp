@@ -11,8 +11,11 @@
 // <p>/proof/; -json FILE appends the result line.
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/prp_cli.cpp -ldl -lgmp -o mi355_prp
-//   ./mi355_prp <p> | -worktodo FILE  [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER]
-//               [-json FILE] [-lib path/to/libmi355_engine.so]
+//   ./mi355_prp <p> | -worktodo FILE  [-d DEVICE] [-ll | -llsafe [-llsafe_block B]] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR]
+//               [-backup N] [-proof POWER] [-json FILE] [-lib path/to/libmi355_engine.so]
+// -d DEVICE is the reference's device selector (src/io/CliParser.cpp:198): BASELINE configs[4] is eight of these processes, `-d i
+// -worktodo file_i`, one per GPU.  -llsafe is the Lucas-Lehmer test with error detection by block re-computation
+// (src/modes/RunLlSafeMarin.cpp:95-392, run_ll_safe below).
 #include <cmath>
 #include <csignal>
 #include <cstdio>
@@ -36,13 +39,73 @@ static std::vector<uint32_t> residue_words(engine* eng, size_t reg, uint32_t p) 
   return fmt::pack_words(v, p);
 }
 
+// Lucas-Lehmer with error detection by block re-computation (src/modes/RunLlSafeMarin.cpp:95-392; prmers_amd/prp.py run_ll_safe is the
+// Python twin).  V follows x -> x^2 - 2 from 4, U accumulates the product of the V's (set_multiplicand + mul per iteration, :257-260);
+// every B = p / sqrt(p) iterations (or -llsafe_block) the block is recomputed from the last good (V, U) and both pairs must agree
+// (:268-296), otherwise the state rolls back to the block start (:297-318).  -erroriter injects V -= 2 once (:245-255).
+static int run_ll_safe(engine* eng, uint32_t p, uint64_t block, uint64_t erroriter, uint64_t maxiters, const std::string& json_file) {
+  const size_t RV = 0, RU = 1, RVC = 2, RUC = 3, RVCHK = 4, RUCHK = 5, RTMP = 6;   // RunLlSafeMarin.cpp:20-28
+  const uint64_t total = p >= 2 ? uint64_t(p) - 2 : 0;
+  eng->set(RV, 4); eng->set(RU, 2);
+  eng->copy(RVC, RV); eng->copy(RUC, RU); eng->copy(RVCHK, RVC); eng->copy(RUCHK, RUC);
+  uint64_t B = block ? block : uint64_t(double(p) / std::sqrt(double(p)));
+  if (B < 1) B = 1;
+  if (B > total && total) B = total;
+  auto step = [&](size_t rv, size_t ru) { eng->set_multiplicand(RTMP, rv); eng->mul(ru, RTMP); eng->square_mul(rv); eng->sub(rv, 2); };
+  bool errordone = false, complete = true;
+  uint64_t itersave = 0, errors = 0, checks = 0, done = 0;
+  for (uint64_t iter = 0; iter < total; ++iter) {
+    if (maxiters && done >= maxiters) { complete = false; break; }
+    if (g_interrupted) { std::printf("\nInterrupted by user at iteration %llu\n", (unsigned long long)iter); return 0; }
+    if (erroriter && iter + 1 == erroriter && !errordone) { errordone = true; eng->sub(RV, 2); std::printf("Injected error at iteration %llu\n", (unsigned long long)(iter + 1)); }
+    step(RV, RU);
+    ++done;
+    if ((iter + 1) % B == 0 || iter + 1 == total) {
+      const uint64_t blk = ((iter + 1) % B == 0) ? B : (iter + 1) - itersave;
+      eng->copy(RVCHK, RVC); eng->copy(RUCHK, RUC);
+      for (uint64_t z = 0; z < blk; ++z) step(RVCHK, RUCHK);
+      ++checks;
+      // the reference compares mpz read-backs (:281-293); is_equal compares the canonical forms on the device
+      if (!(eng->is_equal(RVCHK, RV) && eng->is_equal(RUCHK, RU))) {
+        std::printf("[Error check] Mismatch \n[Error check] Check FAILED! iter=%llu\n[Error check] Restore iter=%llu\n", (unsigned long long)iter, (unsigned long long)itersave);
+        if (++errors > 64) { std::fprintf(stderr, "Error: %llu failed block checks, giving up\n", (unsigned long long)errors); return 1; }
+        eng->copy(RV, RVC); eng->copy(RU, RUC);
+        iter = itersave - 1;   // (wraps to -1 for itersave = 0: the loop increment brings it back to 0, as :305-311)
+      } else {
+        std::printf("[Error check] Check passed! iter=%llu\n", (unsigned long long)iter);
+        eng->copy(RVC, RV); eng->copy(RUC, RU);
+        itersave = iter + 1;
+      }
+    }
+  }
+  engine::digit d(eng, RV);
+  const bool is_mp = d.equal_to_Mp();
+  const bool prime = complete && (d.equal_to(0) || is_mp);
+  std::vector<uint32_t> W = residue_words(eng, RV, p);
+  if (prime && is_mp) std::fill(W.begin(), W.end(), 0u);   // the all-ones vector stands for 0 (:335-338)
+  std::printf("M%u LL-safe: %s  res64=%s  checks=%llu errors=%llu  n=%zu\n", p, complete ? (prime ? "prime" : "composite") : "partial run",
+              fmt::res64_hex(W).c_str(), (unsigned long long)checks, (unsigned long long)errors, eng->get_size());
+  if (complete) {
+    fmt::ResultInfo r; r.exponent = p; r.ll = true; r.is_prime = prime; r.res64 = fmt::res64_hex(W); r.res2048 = fmt::res2048_hex(W);
+    r.gerbicz_errors = unsigned(errors); r.fft_length = unsigned(eng->get_size());
+    const std::string line = fmt::result_json(r);
+    std::printf("%s\n", line.c_str());
+    if (!json_file.empty()) { std::ofstream f(json_file, std::ios::app); f << line << "\n"; }
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: %s <p> | -worktodo FILE [-ll] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER] [-json FILE] [-fft SPEC] [-lib so]\n", argv[0]); return 2; }
+  if (argc < 2) { std::fprintf(stderr, "usage: %s <p> | -worktodo FILE [-d DEVICE] [-ll | -llsafe [-llsafe_block B]] [-erroriter N] [-checklevel L] [-maxiters K] [-ckpt DIR] [-backup N] [-proof POWER] [-json FILE] [-fft SPEC] [-lib so]\n", argv[0]); return 2; }
   uint32_t p = uint32_t(std::strtoul(argv[1], nullptr, 10));
-  bool ll = false; uint64_t erroriter = 0, checklevel = 0, maxiters = 0, backup = 0; std::string lib, worktodo, ckpt_dir, json_file, fft; uint32_t proof_power = 0;
+  bool ll = false, llsafe = false; uint64_t erroriter = 0, checklevel = 0, maxiters = 0, backup = 0, llsafe_block = 0; std::string lib, worktodo, ckpt_dir, json_file, fft; uint32_t proof_power = 0;
+  size_t device = 0;
   fmt::WorkEntry entry;
   for (int i = 1; i < argc; ++i) {
-    if (!std::strcmp(argv[i], "-ll")) ll = true;
+    if (!std::strcmp(argv[i], "-ll") || !std::strcmp(argv[i], "-llunsafe")) ll = true;
+    else if (!std::strcmp(argv[i], "-llsafe")) { ll = true; llsafe = true; }
+    else if (!std::strcmp(argv[i], "-llsafe_block") && i + 1 < argc) llsafe_block = std::strtoull(argv[++i], nullptr, 10);
+    else if (!std::strcmp(argv[i], "-d") && i + 1 < argc) device = size_t(std::strtoul(argv[++i], nullptr, 10));   // src/io/CliParser.cpp:198
     else if (!std::strcmp(argv[i], "-worktodo") && i + 1 < argc) worktodo = argv[++i];
     else if (!std::strcmp(argv[i], "-fft") && i + 1 < argc) fft = argv[++i];   // e.g. crt:9 (the reference's -fft, README.md:907-926)
     else if (!std::strcmp(argv[i], "-ckpt") && i + 1 < argc) ckpt_dir = argv[++i];
@@ -63,7 +126,8 @@ int main(int argc, char** argv) {
   std::signal(SIGINT, on_signal);
   std::signal(SIGTERM, on_signal);
   try {
-    std::unique_ptr<engine> eng(new engine_hip(p, 8, 0, false, lib, fft));
+    std::unique_ptr<engine> eng(new engine_hip(p, 8, device, false, lib, fft));
+    if (llsafe) return run_ll_safe(eng.get(), p, llsafe_block, erroriter, maxiters, json_file);
     const size_t R0 = 0, R1 = 1, R2 = 2, R3 = 3, R4 = 4, R5 = 5, RBASE = 6, RTMP = 7;
     eng->set(R1, 1);
     eng->set(R0, ll ? 4 : 3);

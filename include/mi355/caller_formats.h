@@ -152,20 +152,27 @@ inline bool save_gerbicz_state(const std::string& ckpt_path, uint32_t iteration,
   std::memcpy(b + 32, &crc, 4);
   const std::string fresh = ckpt_path + ".gl.new";
   { std::ofstream f(fresh, std::ios::binary); f.write(reinterpret_cast<const char*>(b), 36); if (!f.good()) return false; }
+  // the side file rotates with the checkpoint (<ckpt>.gl.old belongs to <ckpt>.old), so a resume from the older generation -- a torn main
+  // checkpoint, or a crash between the two renames -- still finds the rollback point that generation was verified from
   std::error_code ec;
+  if (std::filesystem::exists(ckpt_path + ".gl", ec)) std::filesystem::rename(ckpt_path + ".gl", ckpt_path + ".gl.old", ec);
   std::filesystem::rename(fresh, ckpt_path + ".gl", ec);
   return !ec;
 }
+// the rollback point of the checkpoint written at `iteration`, from whichever generation of the side file names that iteration
 inline bool load_gerbicz_state(const std::string& ckpt_path, uint32_t iteration, GerbiczState& g) {
-  std::ifstream f(ckpt_path + ".gl", std::ios::binary);
-  unsigned char b[37];
-  f.read(reinterpret_cast<char*>(b), 37);
-  if (f.gcount() != 36) return false;
-  uint32_t magic, it, crc;
-  std::memcpy(&magic, b, 4); std::memcpy(&it, b + 4, 4); std::memcpy(&crc, b + 32, 4);
-  if (magic != kGerbiczMagic || it != iteration || crc != crc32_update(0, b, 32)) return false;
-  std::memcpy(&g.itersave, b + 8, 8); std::memcpy(&g.jsave, b + 16, 8); std::memcpy(&g.checkpass, b + 24, 8);
-  return true;
+  for (const char* suffix : {".gl", ".gl.old"}) {
+    std::ifstream f(ckpt_path + suffix, std::ios::binary);
+    unsigned char b[37];
+    f.read(reinterpret_cast<char*>(b), 37);
+    if (f.gcount() != 36) continue;
+    uint32_t magic, it, crc;
+    std::memcpy(&magic, b, 4); std::memcpy(&it, b + 4, 4); std::memcpy(&crc, b + 32, 4);
+    if (magic != kGerbiczMagic || it != iteration || crc != crc32_update(0, b, 32)) continue;
+    std::memcpy(&g.itersave, b + 8, 8); std::memcpy(&g.jsave, b + 16, 8); std::memcpy(&g.checkpass, b + 24, 8);
+    return true;
+  }
+  return false;
 }
 
 // ---- worktodo.txt (WorktodoParser.cpp:98-104,331-348): PRP=[aid,]k,b,n,c[,...] / PRPDC= / Test=[aid,]p[,...] / DoubleCheck= ----

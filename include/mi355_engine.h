@@ -74,7 +74,9 @@ MI355_ENGINE_API int mi355_engine_square_mul_copy(mi355_engine_handle handle, si
 MI355_ENGINE_API int mi355_engine_mul_copy(mi355_engine_handle handle, size_t dst, size_t src, size_t dst_copy, uint32_t factor);
 /* count x { reg = reg^2 * factor; reg -= sub } -- the run of squarings a PRP (sub = 0) or Lucas-Lehmer (sub = 2) loop issues between two
    checks (src/modes/RunPrpOrLlMarin.cpp:338-409: one square_mul, and for LL one sub, per iteration).  Same result as the loop of
-   mi355_engine_square_mul / mi355_engine_sub_u32 calls; transforms of at most 2^20 words run it as ONE cooperative launch. */
+   mi355_engine_square_mul / mi355_engine_sub_u32 calls, issued by the library in one call (no per-iteration trip through the FFI; an LL
+   subtraction rides on the next front sweep).  (A one-cooperative-launch form for transforms of at most 2^20 words was built and measured
+   slower than three launches per squaring; it is not in this library: DESIGN.md 5.2c.) */
 MI355_ENGINE_API int mi355_engine_square_mul_n(mi355_engine_handle handle, size_t reg, uint32_t factor, size_t count, uint32_t sub);
 
 /* ---- rest of the engine surface the Marin callers use ---- */

@@ -121,6 +121,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     }
   }
 
+#if defined(MI355_EXPERIMENTAL)
   {
     // transforms whose tiles are all resident at once: one cooperative launch per run of squarings instead of three launches per
     // squaring (kernels.hip k_coop).  Opt-in (MI355_COOP=1): measured slower on MI355X -- 0.044 ms per squaring at C2 inside one launch
@@ -137,6 +138,7 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
       if (cb && std::atoi(cb) > 1) coop_batch_ = size_t(std::atoi(cb));
     }
   }
+#endif
 
   // digit widths in natural order (ibdwt.h:127-132), s_j = p*j mod n kept incrementally
   width_.resize(pl_.n);
@@ -160,7 +162,9 @@ Engine::~Engine() {
   if (f0_) (void)hipFree(f0_);
   if (split_) (void)hipFree(split_);
   if (canon_) (void)hipFree(canon_);
+#if defined(MI355_EXPERIMENTAL)
   if (coop_flags_) (void)hipFree(coop_flags_);
+#endif
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -178,6 +182,7 @@ void Engine::sync() {
   coop_check();
 }
 
+#if defined(MI355_EXPERIMENTAL)
 // The grid barrier of k_coop gives up after 0.2 s and raises the error word; the results of that launch are garbage.
 void Engine::coop_check() {
   if (coop_failed_) throw std::runtime_error("cooperative squaring kernel: a grid barrier timed out earlier; the engine's registers are not valid");
@@ -202,6 +207,7 @@ void Engine::coop_launch(size_t r, uint32_t a, size_t count, uint32_t sub_next) 
     count -= c;
   }
 }
+#endif
 
 void Engine::normalize(size_t r) {
   if (kind_[r] != kDigits) return;
@@ -498,11 +504,13 @@ void Engine::copy(size_t dst, size_t src) {
 
 void Engine::square_chain(size_t r, uint32_t a, hipEvent_t* ev) {
   if (ev) HIPCHK(hipEventRecord(ev[0], stream_));
+#if defined(MI355_EXPERIMENTAL)
   if (coop_groups_ && pending_sub_[r] < (1u << 30)) {   // one launch: the whole squaring sits in slot 0
     coop_launch(r, a, 1, 0);
     if (ev) for (int k = 1; k <= 4; ++k) HIPCHK(hipEventRecord(ev[k], stream_));
     return;
   }
+#endif
   run_front(r);
   if (ev) HIPCHK(hipEventRecord(ev[1], stream_));
   run_middle(work(), nullptr, work(), 0, 0);
@@ -538,7 +546,9 @@ void Engine::square_mul_n(size_t r, uint32_t a, size_t count, uint32_t sub) {
   if (a == 0) throw std::runtime_error("square_mul_n: factor must be >= 1");
   if (count == 0) return;
   HIPCHK(hipSetDevice(device_));
+#if defined(MI355_EXPERIMENTAL)
   if (coop_groups_ && pending_sub_[r] < (1u << 30) && sub < (1u << 30)) { coop_launch(r, a, count, sub); return; }
+#endif
   for (size_t i = 0; i < count; ++i) { square_chain(r, a, nullptr); if (sub) sub_u32(r, sub); }
 }
 
@@ -688,7 +698,7 @@ void Engine::sub_u32(size_t r, uint32_t v) {
   need_digits(r, "sub");
   if (v == 0) return;
   HIPCHK(hipSetDevice(device_));
-  if ((v2cols_ || coop_groups_) && uint64_t(pending_sub_[r]) + v < (1u << 30)) { pending_sub_[r] += v; return; }  // folded into the next front / middle sweep
+  if ((v2cols_ || coop_on()) && uint64_t(pending_sub_[r]) + v < (1u << 30)) { pending_sub_[r] += v; return; }  // folded into the next front / middle sweep
   // the small subtraction only touches the digit vector (cyclic borrow), so run carries that are still pending
   // for the next front sweep can stay pending: value = digits + carries - v either way
   if (!(kind_[r] == kDigits && pl_.C >= 2 && !pending_sub_[r])) normalize(r);
@@ -734,6 +744,19 @@ void Engine::set_checkpoint(const void* data, size_t size) {
 
 // ---- measurement ----------------------------------------------------------------------------
 
+namespace {
+struct EventPool {   // HIP events owned for the length of one measurement
+  std::vector<hipEvent_t> evs;
+  hipEvent_t make() {
+    hipEvent_t e = nullptr;
+    HIPCHK(hipEventCreate(&e));
+    evs.push_back(e);
+    return e;
+  }
+  ~EventPool() { for (hipEvent_t e : evs) (void)hipEventDestroy(e); }
+};
+}  // namespace
+
 const char* Engine::kernel_name(size_t k) {
   static const char* names[kKernels] = {"k_front", "k_middle", "k_back", "k_carry_fix", "k_sub_small", "event_overhead"};
   return k < kKernels ? names[k] : "";
@@ -747,13 +770,16 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
   need_digits(r, "time_square_mul");
   if (a == 0 || iters == 0) throw std::runtime_error("time_square_mul: factor and iters must be >= 1");
   HIPCHK(hipSetDevice(device_));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  EventPool pool;   // destroys its events on every way out (a HIPCHK that throws mid-batch used to leak them)
+  const hipEvent_t e0 = pool.make(), e1 = pool.make();
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipEventRecord(e0, stream_));
+#if defined(MI355_EXPERIMENTAL)
   if (coop_groups_ && coop_batch_ > 1) {   // MI355_COOP_BATCH squarings per launch (what a PRP / LL loop between two checks does)
     for (size_t done = 0; done < iters;) { const size_t c = std::min(coop_batch_, iters - done); square_mul_n(r, a, c, sub); done += c; }
-  } else {
+  } else
+#endif
+  {
     for (size_t i = 0; i < iters; ++i) {
       square_chain(r, a, nullptr);
       if (sub) sub_u32(r, sub);
@@ -764,26 +790,24 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   if (total_ms) *total_ms = ms;
-  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
 
   if (kernel_ms && kcount) {
     for (size_t k = 0; k < kcount; ++k) kernel_ms[k] = 0;
     const size_t reps = std::min<size_t>(iters, 64);
     const size_t per = 6;
     std::vector<hipEvent_t> ev(reps * per);
-    for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+    for (auto& x : ev) x = pool.make();
     // cost of one event record: spacing of back-to-back records on a batch of its own (its size does not depend on `iters`)
     double overhead = 0;
     {
       constexpr size_t kBatch = 64, kSkip = 8;   // the first records carry the queue start-up
       std::vector<hipEvent_t> oe(kBatch);
-      for (auto& x : oe) HIPCHK(hipEventCreate(&x));
+      for (auto& x : oe) x = pool.make();
       for (size_t i = 0; i < kBatch; ++i) HIPCHK(hipEventRecord(oe[i], stream_));
       HIPCHK(hipStreamSynchronize(stream_));
       float t = 0;
       HIPCHK(hipEventElapsedTime(&t, oe[kSkip], oe[kBatch - 1]));
       overhead = double(t) / double(kBatch - 1 - kSkip);
-      for (auto& x : oe) HIPCHK(hipEventDestroy(x));
     }
     for (size_t i = 0; i < reps; ++i) {
       square_chain(r, a, &ev[i * per]);
@@ -797,10 +821,9 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
         HIPCHK(hipEventElapsedTime(&t, ev[i * per + k], ev[i * per + k + 1]));
         kernel_ms[k] += double(t) / double(reps);
       }
-    for (auto& x : ev) HIPCHK(hipEventDestroy(x));
     // which of the five slots hold a kernel on this path
     const bool fix_now = !v2cols_ && pl_.C < 2;                        // k_carry_fix right after the back sweep
-    const bool coop = coop_groups_ != 0;                               // one launch (slot 0) for the whole squaring
+    const bool coop = coop_on();                                       // (experimental build) one launch (slot 0) for the whole squaring
     const bool sub_kernel = sub != 0 && !((v2cols_ || coop) && sub < (1u << 30));          // k_sub_small (else folded into the next front sweep)
     const bool launched[5] = {true, !coop, !coop, fix_now && !coop, sub_kernel};
     for (size_t k = 0; k < 5 && k < kcount; ++k) kernel_ms[k] = launched[k] ? std::max(0.0, kernel_ms[k] - overhead) : -1.0;

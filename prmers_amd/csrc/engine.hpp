@@ -23,7 +23,11 @@ class Engine {
   Engine& operator=(const Engine&) = delete;
 
   const Plan& plan() const { return pl_; }
+#if defined(MI355_EXPERIMENTAL)
   std::string describe() const { return pl_.describe() + (coop_groups_ ? ":coop=" + std::to_string(coop_groups_) : std::string()); }
+#else
+  std::string describe() const { return pl_.describe(); }
+#endif
   size_t n() const { return pl_.n; }
   size_t word_count() const { return (size_t(pl_.p) + 31) / 32; }
   size_t reg_count() const { return nregs_; }
@@ -39,7 +43,8 @@ class Engine {
   void prepare(size_t dst, size_t src);
   void square_mul(size_t r, uint32_t a);
   // count x { square_mul(r, a); sub(r, sub) } -- the inner loop of a PRP (sub = 0) or Lucas-Lehmer (sub = 2) run between two checks.
-  // On transforms of at most 2^20 words it is ONE cooperative launch (kernels.hip k_coop), elsewhere the loop of launches it stands for.
+  // One call for the whole run: the loop of launches it stands for (the one-cooperative-launch form of the small transforms was measured
+  // slower and lives only in the experimental build: make exp, MI355_COOP=1).
   void square_mul_n(size_t r, uint32_t a, size_t count, uint32_t sub);
   void mul(size_t dst, size_t src, uint32_t a);
   void add(size_t dst, size_t src);
@@ -86,8 +91,14 @@ class Engine {
   bool canon_flags_ok(uint32_t (&flags)[4]);    // reads the flag words; false: fall back to the host carry
   void write_values(size_t dst, const std::vector<uint32_t>& natural);
   void square_chain(size_t r, uint32_t a, hipEvent_t* ev);
+#if defined(MI355_EXPERIMENTAL)
   void coop_launch(size_t r, uint32_t a, size_t count, uint32_t sub_next);   // count squarings in one cooperative launch (coop_groups_ != 0)
   void coop_check();                                                         // throws when a grid barrier of an earlier launch timed out
+  bool coop_on() const { return coop_groups_ != 0; }
+#else
+  void coop_check() {}
+  static constexpr bool coop_on() { return false; }
+#endif
   uint64_t* cbuf(size_t r) { return cb_[r]; }
   uint64_t* take_spare_cbuf();                      // carry-word buffers are handed around like the register slots
   void adopt_cbuf(size_t r, uint64_t* fresh);       // r's pending carries are now in `fresh`; its old buffer becomes spare
@@ -122,12 +133,14 @@ class Engine {
   std::vector<uint32_t> stage_;  // host staging (one register of digits)
   uint32_t* canon_ = nullptr;    // device scratch of the canonicalisation: work arrays + two outputs of n digits (lazy)
   bool host_carry_ = false;      // MI355_HOST_CARRY=1: compare / res64 / read-back through the host (A/B tests)
+#if defined(MI355_EXPERIMENTAL)
   // one-launch squarings of the small transforms (kernels.hip k_coop): grid size (0: not served / MI355_COOP=0), barrier words
   // [groups] + error word, barriers passed so far, squarings per launch in time_square_mul (MI355_COOP_BATCH, A/B and bench)
   uint32_t coop_groups_ = 0, coop_epoch_ = 0, coop_fault_ = 0;
   uint32_t* coop_flags_ = nullptr;
   size_t coop_batch_ = 1;
   bool coop_used_ = false, coop_failed_ = false;
+#endif
 };
 
 }  // namespace mi355

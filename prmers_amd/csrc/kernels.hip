@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(1024) k_back(DevPlan pl, const uint64_t* __res
   back_body<EXT, false>(pl, Win, digits, cbuf, a, ext, xcd_tile(pl, blockIdx.x, gridDim.x), reinterpret_cast<P2*>(smem_raw), threadIdx.x, blockDim.x);
 }
 
+#if defined(MI355_EXPERIMENTAL)   // measured slower than three launches: only in libmi355_engine_exp.so (make exp), not in the product library
 // ---------------------------------------------------------------------------------------------
 // One launch per squaring (or per run of squarings) for transforms whose tiles all fit on the chip at once: n <= 2^20 words has at
 // most 256 column tiles and 512 rows, a launch of the three kernels above lasts as long as ONE tile's dependent stream (5-6 us) plus
@@ -511,8 +512,12 @@ constexpr uint64_t kCoopTimeoutTicks = 20000000ull;
 
 __device__ __forceinline__ bool grid_sync(uint32_t* flags, uint32_t* err, uint32_t ngroups, uint32_t epoch) {
   __shared__ uint32_t ok_sh;
-  // the sweeps' hand-over data travels in sc1 stores (st64<true>): once they are acknowledged (vmcnt = 0, which the workgroup-scope
-  // release waits for) they are at the memory side, where the sc1 loads of the next sweep find them -- no L2 maintenance here
+  // the sweeps' hand-over data travels in sc1 stores (st64<true>): once they are acknowledged they are at the memory side, where the
+  // sc1 loads of the next sweep find them -- no L2 maintenance here.  Every wave drains its OWN stores (s_waitcnt vmcnt(0)) before the
+  // barrier that precedes the flag store: a workgroup-scope release fence does not wait for vmcnt on gfx950 without tgsplit (ADVICE r03:
+  // the ISA had only lgkmcnt(0) on this path, so another XCD could see the epoch before the data had landed); tests/test_isa_hazards.py
+  // checks that the wait is in the generated code.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -565,6 +570,8 @@ __global__ void __launch_bounds__(1024) k_coop(DevPlan pl, CoopArgs ca) {
     if (it + 1 < ca.count && !grid_sync(ca.flags, ca.err, G, ++epoch)) return;
   }
 }
+
+#endif   // MI355_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------------------------
 // Columns too long for LDS: M1 = 5 L1 with 16 M1 bytes above a CU's 160 KiB -- n = 5 * 2^26, the largest entry of the reference's
@@ -862,6 +869,7 @@ hipError_t configure_split(const DevPlan& pl) {
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_split_b), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
 }
+#if defined(MI355_EXPERIMENTAL)
 // one cooperative launch for `count` squarings: supported when the generic kernels serve the plan with run carries folded into the front
 // sweep (C >= 2, no split columns) and a grid of max(tiles, rows) work-groups is resident at once
 static inline uint32_t coop_threads(const DevPlan& pl) { return std::max(block_for_small(pl, size_t(pl.M1) * pl.C), block_for_small(pl, pl.M2)); }
@@ -887,6 +895,7 @@ hipError_t launch_coop(const DevPlan& pl, uint32_t groups, uint32_t* digits, uin
   void* args[2] = {&plc, &ca};
   return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_coop), dim3(groups), dim3(coop_threads(pl)), args, unsigned(coop_lds(pl)), s);
 }
+#endif   // MI355_EXPERIMENTAL
 hipError_t launch_linear(const DevPlan& pl, const LinArgs& la, hipStream_t s) {
   const size_t runs = size_t(pl.M1) * (pl.M2 / pl.C);
   hipLaunchKernelGGL(k_linear, dim3((runs + 255) / 256), dim3(256), 0, s, pl, la);

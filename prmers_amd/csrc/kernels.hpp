@@ -49,12 +49,14 @@ hipError_t launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_
 hipError_t launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, hipStream_t s);
 hipError_t launch_carry_fix(const DevPlan& pl, uint32_t* digits, const uint64_t* cbuf, hipStream_t s);
+#if defined(MI355_EXPERIMENTAL)   // libmi355_engine_exp.so only (make exp): measured slower than three launches, DESIGN.md 5.2c
 // `count` squarings in ONE cooperative launch (kernels.hip k_coop): grid size for this plan, or 0 when the plan is not served
 uint32_t coop_groups(const DevPlan& pl, int device);
 // flags: `groups` barrier words, err: error word (both device-visible, zero at first use); epoch0: barriers passed so far on these flags
 // (each squaring passes 3, the last one of a launch 2); sub: subtracted before the first squaring, sub_next before each later one
 hipError_t launch_coop(const DevPlan& pl, uint32_t groups, uint32_t* digits, uint64_t* cbuf, bool carry_in, uint64_t* W, uint32_t a, uint32_t sub, uint32_t sub_next,
                        uint32_t count, uint32_t* flags, uint32_t* err, uint32_t epoch0, uint32_t fault, hipStream_t s);   // fault: test hook, see CoopArgs
+#endif
 // columns of 5 L1 pairs that do not fit LDS (n = 5 * 2^26): the radix-5 stage through a second work buffer U (8 n bytes), C = 1
 hipError_t configure_split(const DevPlan& pl);
 hipError_t launch_front_split(const DevPlan& pl, const uint32_t* digits, uint64_t* U, uint64_t* W, hipStream_t s);

@@ -43,11 +43,12 @@ def check_boundaries(entries, checklevel):
 
 
 class StatusReducer:
-    """all_reduce of {ok (MIN), errors (SUM), iterations (SUM)}; a no-op without a process group."""
+    """all_reduce of {ok (MIN), errors (SUM), iterations (SUM)}; a no-op without a process group.  With a process group it always goes
+    through the backend, also at world size 1 (one rank on one GPU: the same RCCL calls an eight-rank run issues)."""
 
     def __init__(self, device="cpu"):
         self.device = device
-        self.on = dist.is_initialized() and dist.get_world_size() > 1
+        self.on = dist.is_initialized()
         self.lock = threading.Lock()
 
     def reduce(self, ok, errors, iters):
@@ -86,7 +87,7 @@ def run_sharded(worktodo_lines, make_engine, device="cpu", max_iters=None, check
     # boundary reductions only when every rank will reach the same number of them (else at exit only)
     per_rank_checks = [sum(check_boundaries(entries[r::world], checklevel)) for r in range(world)]
     lockstep = (sync_checks is True) or (sync_checks == "auto" and per_gpu == 1 and max_iters is None and checklevel > 0 and
-                                         ckpt_dir is None and world > 1 and len(set(per_rank_checks)) == 1)
+                                         ckpt_dir is None and dist.is_initialized() and len(set(per_rank_checks)) == 1)
     state = {"ok": 1, "errors": 0, "iters": 0}
     state_lock = threading.Lock()
     results = []
@@ -176,7 +177,7 @@ def run_sharded(worktodo_lines, make_engine, device="cpu", max_iters=None, check
     status = reducer.reduce(state["ok"], state["errors"], state["iters"])   # always: the reduction at exit
     if on_status:
         on_status(status)
-    if world > 1:
+    if dist.is_initialized():
         gathered = [None] * world
         dist.all_gather_object(gathered, results)
         results = [r for part in gathered for r in part]
@@ -190,6 +191,28 @@ def init_from_env(backend):
         dist.init_process_group(backend)
 
 
+def visible_gpu_count():
+    """GPUs this process may use, counted without initialising the HIP runtime: the KFD topology nodes that have SIMDs (CPU agents have
+    none), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one of them is set."""
+    import glob
+    n = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(props):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            ids = [x for x in val.split(",") if x.strip() != ""]
+            n = min(n, len(ids)) if n else 0
+            break
+    return n
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m prmers_amd.launch", description=__doc__.split("\n\n")[0])
     ap.add_argument("--worktodo", required=True, help="worktodo.txt (PRP= / PRPDC= / Test= / DoubleCheck= lines)")
@@ -199,7 +222,8 @@ def main(argv=None):
     ap.add_argument("--checklevel", type=int, default=0, help="Gerbicz-Li checks every this many block boundaries (0: the reference's automatic rule)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo")
     ap.add_argument("--fft", default=None, help="transform spec handed to every engine: a plan (m2=..,c=..) or crt[:odd][:words=N] for the "
-                    "GF(M61^2) x GF(M31^2) family with a prime-factor axis (the reference's -fft)")
+                    "GF(M61^2) x GF(M31^2) family with a prime-factor axis (the reference's -fft); a bare `crt` picks the radix by the "
+                    "reference's 1.30 / 1.60 size-ratio gates on THIS engine's capacity rule (~34 bits per word: README.md)")
     ap.add_argument("--ckpt-dir", default=None, help="directory of the per-exponent checkpoint files (resume on start, save every "
                     "--backup-interval seconds and on SIGINT / SIGTERM); default: no checkpoints")
     ap.add_argument("--backup-interval", type=float, default=300.0, help="seconds between checkpoints (the reference's -t)")
@@ -216,11 +240,15 @@ def main(argv=None):
             print(json.dumps({"rank": r, "entries": [{"mode": m, "exponent": p} for m, p in entries[r::world]]}))
         return 0
 
-    # rendezvous first: nothing below may touch the GPU before the process group exists
+    # rendezvous first: nothing below may touch the GPU before the process group exists -- so the devices are counted WITHOUT the HIP
+    # runtime (torch.cuda.device_count() only avoids it when its amdsmi path is available): the KFD topology lists the GPU agents
     device = "cpu"
-    ndev = max(1, torch.cuda.device_count())   # (counting devices does not initialise the GPU)
+    ndev = visible_gpu_count()
+    if ndev == 0:
+        sys.stderr.write("error: no GPU visible (no KFD GPU node / empty HIP_VISIBLE_DEVICES): the MI355X engine has no CPU fallback\n")
+        return 2
     gpu = local_rank % ndev                    # more ranks than GPUs: rank i runs on device i mod N (two tests fill each other's launch gaps)
-    if world > 1:
+    if world > 1 or os.environ.get("MI355_FORCE_PROCESS_GROUP") == "1":   # (the variable: a one-rank group, to rehearse the RCCL path on one GPU)
         if args.backend == "nccl":
             if int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) > ndev:
                 sys.stderr.write("error: %d ranks on %d GPU(s): RCCL takes one rank per device; use --backend gloo for the status word\n" % (world, ndev))

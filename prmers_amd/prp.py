@@ -140,25 +140,31 @@ def gerbicz_state_name(ckpt_path):
 
 def save_gerbicz_state(ckpt_path, it, itersave, jsave, checkpass):
     body = struct.pack("<IIQQQ", GL_MAGIC, it, itersave, jsave, checkpass)
-    tmp = gerbicz_state_name(ckpt_path) + ".new"
+    name = gerbicz_state_name(ckpt_path)
+    tmp = name + ".new"
     with open(tmp, "wb") as f:
         f.write(body + struct.pack("<I", zlib.crc32(body) & 0xFFFFFFFF))
-    os.replace(tmp, gerbicz_state_name(ckpt_path))
+    # the side file rotates with the checkpoint (<ckpt>.gl.old belongs to <ckpt>.old): a resume from the older generation -- a torn main
+    # checkpoint, or a crash between the renames -- still finds the rollback point that generation was verified from
+    if os.path.exists(name):
+        os.replace(name, name + ".old")
+    os.replace(tmp, name)
 
 
 def load_gerbicz_state(ckpt_path, it):
-    """-> (itersave, jsave, checkpass) if the side file belongs to the checkpoint of iteration `it`, else None."""
-    try:
-        raw = open(gerbicz_state_name(ckpt_path), "rb").read()
-    except OSError:
-        return None
+    """-> (itersave, jsave, checkpass) from whichever generation of the side file belongs to the checkpoint of iteration `it`, else None."""
     n = struct.calcsize("<IIQQQ")
-    if len(raw) != n + 4 or struct.unpack("<I", raw[n:])[0] != (zlib.crc32(raw[:n]) & 0xFFFFFFFF):
-        return None
-    magic, sit, itersave, jsave, checkpass = struct.unpack("<IIQQQ", raw[:n])
-    if magic != GL_MAGIC or sit != it:
-        return None
-    return int(itersave), int(jsave), int(checkpass)
+    for name in (gerbicz_state_name(ckpt_path), gerbicz_state_name(ckpt_path) + ".old"):
+        try:
+            raw = open(name, "rb").read()
+        except OSError:
+            continue
+        if len(raw) != n + 4 or struct.unpack("<I", raw[n:])[0] != (zlib.crc32(raw[:n]) & 0xFFFFFFFF):
+            continue
+        magic, sit, itersave, jsave, checkpass = struct.unpack("<IIQQQ", raw[:n])
+        if magic == GL_MAGIC and sit == it:
+            return int(itersave), int(jsave), int(checkpass)
+    return None
 
 
 MAX_GERBICZ_ERRORS = 64   # a run that keeps failing its checks is stopped (hardware that is not fit for the job)
@@ -242,12 +248,9 @@ def run_prp_or_ll(eng, p, mode="prp", gerbicz=True, erroriter=0, checklevel=0, m
     ri = 0
     gl = None
     if ckpt_path:
-        got = load_checkpoint(ckpt_path, eng, p, mode)
+        got = load_checkpoint(ckpt_path, eng, p, mode) or load_checkpoint(ckpt_path + ".old", eng, p, mode)
         if got:
-            gl = load_gerbicz_state(ckpt_path, got[0])
-        else:
-            got = load_checkpoint(ckpt_path + ".old", eng, p, mode)
-        if got:
+            gl = load_gerbicz_state(ckpt_path, got[0])   # the side-file generation that names this checkpoint's iteration
             ri = got[0]
             log("Resuming from a checkpoint.")
     if ri == 0 and resume is None:

@@ -22,6 +22,7 @@ if which == "launch":
     import orc
     prmers_amd.Engine = lambda p, regs, device=0, plan=None: orc.OracleEngine(p, regs)
     from prmers_amd import launch
+    launch.visible_gpu_count = lambda: 1   # (the stub engine needs no GPU; the real launcher refuses to start without one)
     sys.exit(launch.main(argv))
 
 if which == "bench":

@@ -175,6 +175,31 @@ def test_cpp_driver_resume_rollback_and_sigint_on_the_oracle(tmp_path):
     assert line["errors"] == {"gerbicz": 0}
 
 
+def test_cpp_driver_ll_safe_on_the_oracle(tmp_path):
+    """examples/prp_cli.cpp -llsafe on CPU (the oracle-backed ABI shim): Lucas-Lehmer with block re-computation
+    (src/modes/RunLlSafeMarin.cpp:95-392) -- verdicts of unit_tests.sh:5-14 exponents, an injected error caught at the block boundary and
+    rolled back to the block start, the same residue as the Python twin (prmers_amd/prp.py run_ll_safe)."""
+    import json
+    exe, shim = _build_cli(str(tmp_path)), _build_oracle_shim(str(tmp_path))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    run = lambda *a: subprocess.run([exe, *a, "-lib", shim], capture_output=True, text=True, cwd=str(tmp_path), env=env)   # noqa: E731
+    o = run("521", "-llsafe", "-llsafe_block", "50", "-erroriter", "120", "-json", "r.json")
+    assert o.returncode == 0, o.stdout + o.stderr
+    assert "Injected error at iteration 120" in o.stdout and "[Error check] Check FAILED! iter=149" in o.stdout and "[Error check] Restore iter=100" in o.stdout
+    assert "LL-safe: prime" in o.stdout and "errors=1" in o.stdout
+    line = json.loads((tmp_path / "r.json").read_text().splitlines()[-1])
+    assert line["status"] == "P" and line["res64"] == "0000000000000000"
+    o = run("523", "-llsafe")
+    assert "LL-safe: composite" in o.stdout and "errors=0" in o.stdout, o.stdout + o.stderr
+    import orc
+    from prmers_amd import prp
+    ref = prp.run_ll_safe(orc.OracleEngine(523, 8), 523)
+    assert ("res64=%s" % ref["res64"]) in o.stdout, (ref["res64"], o.stdout)
+    # an error in the very first block rolls back to iteration 0
+    o = run("127", "-llsafe", "-llsafe_block", "40", "-erroriter", "3")
+    assert "[Error check] Restore iter=0" in o.stdout and "LL-safe: prime" in o.stdout, o.stdout
+
+
 def test_cpp_driver_fails_loudly_without_gpu():
     from prmers_amd import engine as E
     import torch
@@ -199,6 +224,15 @@ def test_cpp_driver_prp_ll_and_fault_injection_on_gpu():
         assert "[Gerbicz Li] Restore iter=0 (j=9940)" in o.stdout and "probably prime" in o.stdout
         assert "probably prime" in run("607", "-ll").stdout
         assert "composite" in run("1001").stdout
+        # -d: the reference's device selector (src/io/CliParser.cpp:198); a device that does not exist fails loudly (exit 2, src/main.cpp:159-164)
+        assert "probably prime" in run("521", "-d", "0").stdout
+        bad = run("521", "-d", "99")
+        assert bad.returncode == 2 and "device" in bad.stderr.lower(), bad.stdout + bad.stderr
+        # LL-safe (src/modes/RunLlSafeMarin.cpp:95-392): block re-computation, an injected error is caught and rolled back
+        o = run("2203", "-llsafe", "-llsafe_block", "100", "-erroriter", "150")
+        assert o.returncode == 0 and "Injected error at iteration 150" in o.stdout and "[Error check] Check FAILED! iter=199" in o.stdout, o.stdout + o.stderr
+        assert "[Error check] Restore iter=100" in o.stdout and "LL-safe: prime" in o.stdout and "errors=1" in o.stdout
+        assert "LL-safe: composite" in run("2207", "-llsafe").stdout
 
 
 REF_INCLUDE = "/root/reference/include"
@@ -422,3 +456,33 @@ def test_automatic_pfa_radix_follows_the_reference_policy_at_the_exact_boundarie
     # BASELINE configs[3]: the automatic plan of p = 205271257 is the radix-3 size of the reference's own table row (README.md:916)
     assert auto(205271257) == (3, 6291456)
     assert resolve_plan(205271257, "crt:9") == "crt-hip:n=9437184:odd=9" and resolve_plan(205271257, "crt:auto") == "crt-hip:n=6291456:odd=3"
+
+
+def test_automatic_pfa_plan_against_the_published_ranges_of_the_reference():
+    """the gap between this engine's automatic plan and the reference's published `pfa:auto` ranges (README.md:907-922), row by
+    row.  The gates are the reference's (1.30 / 1.60), but a size admits fewer bits per word here (worst-case rule log2 n + 2 (p/n + 1) < 92,
+    ~34 bits; the reference's measured tables admit ~39), so: at the START of every radix-3 row the same plan is chosen; at the END of a
+    radix-3 row this engine has already moved to the next stock size; inside the radix-9 rows it takes the radix-3 size 4/3 as large (the
+    radix-9 size no longer admits the exponent).  Residues are identical either way -- only the transform length differs."""
+    from prmers_amd import resolve_plan
+
+    def auto(p):
+        m = re.fullmatch(r"crt-hip:n=(\d+):odd=(\d+)", resolve_plan(p, "crt"))
+        return int(m.group(2)), int(m.group(1))
+
+    # (radix, first p, last p, words) of the reference's table
+    rows = [(3, 10627319, 15724707, 393216), (3, 21071135, 31284264, 786432), (9, 41922069, 46560704, 1179648), (3, 46560705, 62080936, 1572864),
+            (9, 83194017, 92625960, 2359296), (3, 92625961, 123343992, 3145728), (9, 165507233, 183789168, 4718592),
+            (3, 183789169, 244737648, 6291456), (9, 328414017, 365879616, 9437184), (3, 365879617, 487210368, 12582912),
+            (9, 653808129, 725153152, 18874368), (3, 725153153, 965612672, 25165824), (9, 1295872129, 1440869120, 37748736),
+            (9, 2574967041, 2862863872, 75497472)]
+    same = 0
+    for odd, lo, hi, n in rows:
+        if odd == 3:
+            assert auto(lo) == (3, n), (lo, auto(lo))                       # same plan as the reference where the size admits p
+            assert auto(hi) == (1, n // 3 * 4), (hi, auto(hi))              # beyond our capacity of that size: the next stock size
+            same += 1
+        else:
+            assert auto(lo) == auto(hi) == (3, n // 9 * 12), (lo, hi, auto(lo))   # radix-9 row: the radix-3 size above it
+    assert same == 7
+    assert auto(175000001) == (3, 6291456)   # the reference takes pfa9 at 4,718,592 words here (ADVICE r03's example)

@@ -120,6 +120,28 @@ def test_failed_check_after_a_resume_rolls_back_to_the_saved_point(kind, side_fi
     assert r["iterations"] == p
 
 
+def test_resume_from_the_older_generation_keeps_its_rollback_point(tmp_path):
+    """the rollback side file rotates with the checkpoint.  Checkpoints at 4040 and 5050; the main file is then torn, so the
+    run resumes from <ckpt>.old (iteration 4040) -- and a check that fails right after must roll back to the block that generation was
+    verified from (the point stored in <ckpt>.gl.old), not to the resumed mid-block state."""
+    p = 9941
+    path = prp.checkpoint_name(p, "prp", str(tmp_path))
+    e = orc.OracleEngine(p, prp.REGISTERS)
+    prp.run_prp_or_ll(e, p, "prp", checklevel=1, max_iters=5050, ckpt_path=path, backup_every=1010)
+    assert os.path.exists(prp.gerbicz_state_name(path) + ".old")
+    newer, older = prp.load_gerbicz_state(path, 5050), prp.load_gerbicz_state(path, 4040)
+    assert newer is not None and older is not None and older[0] < 4040 < newer[0] < 5050
+    with open(path, "r+b") as f:      # tear the main checkpoint: its CRC no longer matches
+        f.seek(100); f.write(b"\xff" * 8)
+    msgs = []
+    e = orc.OracleEngine(p, prp.REGISTERS)
+    r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, ckpt_path=path, erroriter=4050, log=msgs.append)
+    assert "Resuming from a checkpoint." in msgs and "Injected error at iteration 4050" in msgs
+    restored = [m for m in msgs if m.startswith("[Gerbicz Li] Restore")]
+    assert len(restored) == 1 and restored[0].startswith("[Gerbicz Li] Restore iter=%d " % older[0]), restored
+    assert r["gerbicz_errors"] == 1 and r["complete"] and r["is_prime"] and r["res64"] == "0000000000000001"
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_interrupt_checkpoints_and_the_resume_reaches_the_golden_residue(kind, tmp_path):
     """SIGINT path of the reference (RunPrpOrLlMarin.cpp:296-309): state saved at the iteration the flag is seen, clean

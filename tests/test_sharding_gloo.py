@@ -162,6 +162,21 @@ def _torchrun(tmp_path, *args, timeout=300):
     return subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="1"))
 
 
+def test_launcher_refuses_to_start_without_a_gpu(tmp_path):
+    """the launcher counts its devices without the HIP runtime (KFD topology) and fails with a clear message when none is
+    visible, instead of creating engines on `local_rank % 0`."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    wt = tmp_path / "worktodo.txt"
+    wt.write_text("PRP=1,2,127,-1\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "prmers_amd.launch", "--worktodo", str(wt), "--backend", "gloo"], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert out.returncode == 2 and "no GPU visible" in out.stderr, out.stdout + out.stderr
+    from prmers_amd import launch
+    assert launch.visible_gpu_count() == 0
+
+
 def test_the_torchrun_command_line_of_the_launcher_end_to_end(tmp_path):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... -m prmers_amd.launch --worktodo ...` with the
     engine replaced by the oracle (tests/dist_stub_entry.py): rendezvous, sharding, reductions, gather, the result file with real fft lengths"""

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Checks of the one-cooperative-launch squaring kernel (kernels.hip k_coop), which is NOT in the product library: it was measured
+slower than three launches per squaring and is only built into libmi355_engine_exp.so (`make -C prmers_amd/csrc exp`).
+
+    MI355_ENGINE_LIB=prmers_amd/libmi355_engine_exp.so MI355_COOP=1 python tools/exp_coop_check.py          # on an MI355X box
+
+Digits against the oracle and against the three-launch chain of the same library (MI355_COOP unset), a run of squarings per launch, and
+the barrier time-out path (MI355_COOP_FAULT=1)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402
+from prmers_amd import Engine  # noqa: E402
+from prmers_amd.engine import EngineError  # noqa: E402
+
+CASES = [(127, "m2=2,c=2"), (521, "m2=4,c=2"), (1801, "m2=8,c=4"), (9941, "m2=64,c=8"), (44497, None), (400063, "m2=64,c=4"), (2976221, None),
+         (9815459, None)]
+
+
+def main():
+    if "exp" not in os.environ.get("MI355_ENGINE_LIB", ""):
+        raise SystemExit("set MI355_ENGINE_LIB to libmi355_engine_exp.so (make -C prmers_amd/csrc exp)")
+    os.environ["MI355_COOP"] = "1"
+    for p, plan in CASES:
+        rng = np.random.default_rng(p)
+        x0 = int.from_bytes(rng.bytes((p + 7) // 8), "little") % ((1 << p) - 1)
+        o = orc.Oracle(p, 2); o.set_value(0, x0)
+        with Engine(p, 2, plan=plan) as e:
+            assert ":coop=" in e.describe(), e.describe()
+            e.set_int(0, x0)
+            for it in range(6):
+                e.square_mul(0, 3 if it == 4 else 1); o.square_mul(0, 3 if it == 4 else 1)
+            assert np.array_equal(e.digits(0), o.digits(0)), (p, plan)
+            e.square_mul_n(0, 17); [o.square_mul(0) for _ in range(17)]
+            e.square_mul_n(0, 9, 1, 2)
+            for _ in range(9): o.square_mul(0); o.sub(0, 2)
+            assert np.array_equal(e.digits(0), o.digits(0)), (p, plan)
+        print("ok", p, plan)
+    os.environ["MI355_COOP_FAULT"] = "1"
+    with Engine(9941, 2, plan="m2=16,c=4") as e:
+        e.set(0, 3); e.square_mul(0)
+        try:
+            e.digits(0)
+            raise SystemExit("the barrier time-out was not reported")
+        except EngineError as exc:
+            assert "grid barrier timed out" in str(exc)
+    print("ok barrier time-out reported")
+
+
+if __name__ == "__main__":
+    main()

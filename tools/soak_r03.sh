@@ -9,5 +9,5 @@ python tools/soak.py 332000003 60000 1 2>&1 | grep -v "Check passed" | tail -3  
 python tools/soak.py 9815459 400000 8 2>&1 | grep -v "Check passed" | tail -3          # C2
 python tools/soak_crt.py 1257787 9 4 2>&1 | grep -v "Check passed" | tail -3      # complete PRP of M1257787 on the crt family, radix 9
 python tools/full_prp.py 6972593 2>&1 | tail -3                                                 # complete PRP of M6972593
-MI355_COOP=1 python tools/soak.py 9815459 200000 8 2>&1 | grep -v "Check passed" | tail -3   # C2 through the one-launch kernel (opt-in path): runs of squarings per cooperative launch
+MI355_ENGINE_LIB=prmers_amd/libmi355_engine_exp.so MI355_COOP=1 python tools/soak.py 9815459 200000 8 2>&1 | grep -v "Check passed" | tail -3   # C2 through the one-launch kernel (opt-in path): runs of squarings per cooperative launch
 python tools/soak_crt.py 756839 3 4 2>&1 | grep -v "Check passed" | tail -3          # complete PRP of M756839 on the crt family, radix 3 (fused back + carry)
