@@ -18,8 +18,9 @@
 // set_multiplicand and mul).
 // Value ranges: field values are canonical ([0, P)) except that (a) a negated zero may be P (gf.hpp,
 // mul_pow2) and (b) sums marked LAZY (gfdft.hpp) may be any 64-bit representative; (b) only ever feeds a
-// multiplication, and every kernel's last arithmetic step before a store is a multiplication or a canonical
-// add/sub, so nothing non-canonical other than P reaches an add/sub operand or a digit.
+// multiplication, a shift or the minuend / lazy-sum slot that gfdft.hpp names, and every kernel's last arithmetic step before a store is a
+// multiplication or a canonical add/sub -- except the row kernel's last inverse stage, whose un-folded outputs the back sweep multiplies first --
+// so nothing non-canonical other than P reaches a canonical-only operand or a digit.
 //
 // LDS exchanges (P2 = 16 B slots, index skewed by i + i/8 against bank conflicts):
 //   writer "thread-major": slot t*8 + r          reader: slot j*512 + t'

@@ -46,7 +46,7 @@ __device__ __forceinline__ void seam64_const(P2 (&x)[8]) {
     x[k] = {gf::mul_pow2(x[k].a, s), gf::mul_pow2(x[k].b, s)};
   }
 }
-// FOLD0: the caller left x[1..3] un-folded (dft8 LAZY = 1) because the shifts below accept any operand; wave 0
+// FOLD0: the caller left x[1..3] and x[5] un-folded (dft8 LAZY = 1) because the shifts below accept any operand; wave 0
 // shifts by nothing, so it folds them here instead.
 template <bool INV, bool FOLD0 = false>
 __device__ __forceinline__ void seam64(P2 (&x)[8], uint32_t wave) {
@@ -55,6 +55,7 @@ __device__ __forceinline__ void seam64(P2 (&x)[8], uint32_t wave) {
       if (FOLD0) {
 #pragma unroll
         for (int k = 1; k < 4; ++k) x[k] = {gf::fold(x[k].a), gf::fold(x[k].b)};
+        x[5] = {gf::fold(x[5].a), gf::fold(x[5].b)};
       }
       break;
     case 1: seam64_const<1, INV>(x); break;
