@@ -597,11 +597,12 @@ __global__ void __launch_bounds__(512) k_build_f0(DevPlan pl, uint64_t* __restri
 }
 }  // namespace v2
 
-size_t v2_threads_per_tile(const DevPlan& pl) { return v5_cols_shape(pl) ? v5_threads_per_tile() : 512; }
+size_t v2_threads_per_tile(const DevPlan& pl) { return v5_cols_shape(pl) ? v5_threads_per_tile() : v3_cols_shape(pl) ? v3_threads_per_tile() : 512; }
 
 hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, uint64_t* fbf, uint64_t* fbi, hipStream_t s) {
   const dim3 grid(pl.M2 / pl.C), block(512);
   if (v5_cols_shape(pl)) return v5_build_fourstep(pl, f0f, f0i, fbf, fbi, s);
+  if (v3_cols_shape(pl)) return v3_build_fourstep(pl, f0f, f0i, fbf, fbi, s);
   switch (pl.M1) {
     case 512: hipLaunchKernelGGL(v2::k_build_f0<1>, grid, block, 0, s, pl, f0f, f0i, fbf, fbi); break;
     case 1024: hipLaunchKernelGGL(v2::k_build_f0<2>, grid, block, 0, s, pl, f0f, f0i, fbf, fbi); break;
@@ -615,6 +616,7 @@ hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 // rows of 2048 go two to a tile: only where that still gives at least one work-group per CU (n = 2^21, 5 2^20); below that the generic
 // rows win.  MI355_TUNE bit 6 switches them off (A/B runs)
 bool v2_rows_supported(const DevPlan& pl) {
+  if (v3_rows_shape(pl)) return true;   // rows of 1024: the radix-4 set (kernels_v3.hip)
   if (pl.S2r == nullptr) return false;
   if (pl.M2 == 4096 || pl.M2 == 8192) return true;
   return pl.M2 == 2048 && pl.M1 % 2 == 0 && pl.M1 >= 512 && !(pl.tune & 64);
@@ -622,6 +624,7 @@ bool v2_rows_supported(const DevPlan& pl) {
 // columns: M1 = 512 R, R in {1, 2, 4}, with C = 8 / R pairs per run (one 4096-pair tile per work-group)
 bool v2_cols_supported(const DevPlan& pl) {
   if (v5_cols_shape(pl)) return pl.DI != nullptr;
+  if (v3_cols_shape(pl)) return true;   // columns of 256 x 4: the radix-4 set
   return pl.r5 == 1 && (pl.M1 == 512 || pl.M1 == 1024 || pl.M1 == 2048) && pl.M1 * pl.C == 4096 && pl.M2 >= pl.C * 2 && pl.S1r != nullptr &&
          pl.DI != nullptr;
 }
@@ -641,6 +644,7 @@ hipError_t v2_configure() {
 }
 #undef MI355_SET_LDS
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
+  if (v3_rows_shape(pl)) return v3_launch_middle(pl, Win, Y, Wout, mode, sub, s);
 #define MI355_ROWS(MODE, HH) hipLaunchKernelGGL((v2::k2_rows4096<MODE, HH>), dim3(pl.M1), dim3(512 * HH), HH * v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
   if (pl.M2 == 2048) {   // two rows to a tile
 #define MI355_ROWS_TWO(MODE) hipLaunchKernelGGL((v2::k2_rows4096<MODE, 1, 1>), dim3(pl.M1 / 2), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
@@ -657,6 +661,7 @@ hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
   const dim3 grid(pl.M2 / pl.C), block(512);
   if (v5_cols_shape(pl)) return v5_launch_front(pl, digits, cbuf_in, sub, W, s);
+  if (v3_cols_shape(pl)) return v3_launch_front(pl, digits, cbuf_in, sub, W, s);
   switch (pl.M1) {
     case 512: hipLaunchKernelGGL(v2::k1_cols<1>, grid, block, v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W); break;
     case 1024: hipLaunchKernelGGL(v2::k1_cols<2>, grid, block, v2::kLdsBytes, s, pl, digits, cbuf_in, sub, W); break;
@@ -667,6 +672,7 @@ hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s) {
   const dim3 grid(pl.M2 / pl.C), block(512);
   if (v5_cols_shape(pl)) return v5_launch_back(pl, W, digits, cbuf, a, scale, s);
+  if (v3_cols_shape(pl)) return v3_launch_back(pl, W, digits, cbuf, a, scale, s);
   switch (pl.M1) {
     case 512: hipLaunchKernelGGL(v2::k3_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
     case 1024: hipLaunchKernelGGL(v2::k3_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, scale); break;
@@ -677,6 +683,7 @@ hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits
 hipError_t v2_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s) {
   const dim3 grid(pl.M2 / pl.C), block(512);
   if (v5_cols_shape(pl)) return v5_launch_back_ext(pl, W, digits, cbuf, a, x, s);
+  if (v3_cols_shape(pl)) return v3_launch_back_ext(pl, W, digits, cbuf, a, x, s);
   switch (pl.M1) {
     case 512: hipLaunchKernelGGL(v2::k3_cols_ext<1>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, x); break;
     case 1024: hipLaunchKernelGGL(v2::k3_cols_ext<2>, grid, block, v2::kLdsBytes, s, pl, W, digits, cbuf, a, x); break;

@@ -163,6 +163,9 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
   // take C = 2 wherever the tile still fits the 160 KiB of LDS; beyond that the engine adds a local carry pass
   if (C == 1 && pl.M2 >= 2 && size_t(pl.M1) * 2 * 16 <= 160 * 1024 && pl.n >= (size_t(1) << 19)) C = 2;
   if (pl.split5) C = 1;
+  // columns of 256 run on the register-resident radix-4 kernels with runs of four pairs (kernels_v3.hip): n = 2^20 as 256 x 2048 with
+  // C = 4 takes 0.043 ms per squaring against 0.051 with C = 8 on the generic columns (round 4, profiles/r04_ab_radix4_set.txt)
+  if (pl.r5 == 1 && pl.M1 == 256 && pl.M2 >= 8 && C > 4 && !pl.split5) C = 4;
   if (want_c > 0 && !pl.split5) {
     C = uint32_t(want_c);
     if ((C & (C - 1)) != 0 || C > pl.M2 || size_t(pl.M1) * C > 10240) throw std::runtime_error("bad c in plan spec");
@@ -248,6 +251,22 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
             w |= (wbit | (wrap << 1)) << (2 * (d1 * ND + k));
           }
         pl.DI[T * 512 + t] = w;
+      }
+  }
+  if (pl.r5 == 1 && pl.M1 == 256 && pl.C == 4 && pl.M2 >= 8) {
+    // columns of 256 (kernels_v3.hip): 256 threads per tile, thread t owns the run i1 = t (8 digits, 2 bits each)
+    pl.DI.assign(pl.tiles() * 256, 0u);
+    for (size_t T = 0; T < pl.tiles(); ++T)
+      for (uint32_t t = 0; t < 256; ++t) {
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < 8; ++k) {
+          const uint32_t i1 = t, i2 = uint32_t(T) * 4 + (k >> 1);
+          const uint64_t sb = pl.SB[2 * i2 + (k & 1)], s = (uint64_t(pl.SA[i1]) + sb) % n;
+          const uint64_t wa = (k & 1) ? pl.SA[pl.M1 + i1] : pl.SA[i1], wb = pl.SB[2 * i2];
+          const uint32_t wbit = pl.width_of_s(s) - pl.q, wrap = (wa > 0 && wb > 0 && wa + wb <= n) ? 1u : 0u;
+          w |= (wbit | (wrap << 1)) << (2 * k);
+        }
+        pl.DI[T * 256 + t] = w;
       }
   }
   if (pl.r5 == 5 && pl.M1 == 1280 && pl.C == 4 && pl.M2 >= 8) {

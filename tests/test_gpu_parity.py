@@ -32,6 +32,10 @@ SMALL_CASES = [
     # shapes served by the register-resident radix-8 kernels: rows of 4096, columns of 512 x 8, 1024 x 4, 2048 x 2
     (300007, "m2=4096"), (300007, "m2=8,c=4"), (300007, "m2=16,c=8"), (300007, "m2=4,c=2"), (216091, None),
     (600011, "m2=32,c=8"), (600011, "m2=8,c=2"), (1200007, "m2=64,c=8"),
+    # shapes served by the register-resident radix-4 kernels (kernels_v3.hip, round 4): columns of 256 x 4 (with generic rows and with
+    # their own rows of 1024: p = 9815459 below), rows of 1024 over generic columns of 8 .. 64
+    (86243, "m2=8,c=4"), (132049, "m2=16,c=4"), (300007, "m2=32,c=4"), (756839, "m2=64,c=4"),
+    (300007, "m2=1024"), (600011, "m2=1024"), (1200007, "m2=1024,c=4"), (2976221, "m2=1024"),
     # columns of 1280 = 5 x 256 on the register-resident radix-5 kernels (640 threads per tile), generic and radix-8 rows
     (400063, "m2=8,c=4"), (800283, "m2=16,c=4"), (1600589, "m2=32,c=4"),
     # rows of 8192 (two 4096-point halves under one radix-2 level, 1024 threads)
@@ -241,6 +245,38 @@ def test_c2_9815459_first_iterations():
             e.square_mul(0); o.square_mul(0)
             if it in (0, 20, 40, 59):
                 assert np.array_equal(e.digits(0), o.digits(0)), it
+
+
+@pytest.mark.parametrize("p,n", [(9815459, 1 << 19), (4800007, 1 << 18), (50000017, 5 << 19)])
+def test_radix4_set_full_size_operations(p, n):
+    """The shapes of the register-resident radix-4 kernels at full-size digits (kernels_v3.hip): C2 (columns of 256 x 4 + rows of 1024),
+    n = 2^18 (rows of 1024 over generic columns of 128) and n = 5 2^19 (rows of 1024 under the radix-5 columns): squarings with a factor,
+    the LL step with the subtraction deferred into the next sweep, set_multiplicand / mul (forward-only and multiply modes of the row
+    kernel), the fused back sweeps (mul_add, square_mul_copy) -- digit vectors against the oracle."""
+    o = orc.Oracle(p, 4)
+    rng = np.random.default_rng(p)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    with Engine(p, 4) as e:
+        assert e.n == n == o.n
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        for it in range(3):
+            e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.square_mul(0, 3); o.square_mul(0, 3)
+        e.sub(0, 2); o.sub(0, 2)
+        e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.copy(1, 0); o.copy(1, 0)
+        e.square_mul(1); o.square_mul(1)
+        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)
+        e.mul(0, 2); o.mul(0, 2)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.mul_add(0, 2, 1); o.mul(0, 2); o.add(0, 1)           # dst = dst * src + add_src (engine.h:65)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.square_mul_copy(0, 3); o.square_mul(0); o.copy(3, 0)   # engine.h:81
+        assert np.array_equal(e.digits(0), o.digits(0)) and np.array_equal(e.digits(3), o.digits(3))
+        assert e.res64(0) == o.res64(0) and e.is_equal(0, 3)
 
 
 def test_c3_136279841_full_size():

@@ -32,7 +32,7 @@ def test_checker_sees_a_planted_hazard_and_accepts_padded_code(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["prmers_amd/csrc/kernels_v2.hip", "prmers_amd/csrc/kernels_v5.hip", "prmers_amd/csrc/kernels.hip", "prmers_amd/csrc/selftest.hip"])
+@pytest.mark.parametrize("src", ["prmers_amd/csrc/kernels_v2.hip", "prmers_amd/csrc/kernels_v3.hip", "prmers_amd/csrc/kernels_v5.hip", "prmers_amd/csrc/kernels.hip", "prmers_amd/csrc/selftest.hip"])
 def test_shipped_kernels_have_no_unpadded_sgpr_hazard(src):
     extra = _v2_flags() if src.endswith("kernels_v2.hip") else ()
     with tempfile.TemporaryDirectory() as td:
