@@ -27,11 +27,27 @@ constexpr uint32_t kThreads = 640, kTile = 5120, kM1 = 1280;
 // (3 + 3 + 2 + 2) is not placed next to a resident one for up to 17 us after a slot has become free (profiles/r03_probe_c4.md: 44 % of
 // the dispatches of a launch, a CU then runs one group for half of its time); twelve are placed within 2 us like the 512-thread groups.
 constexpr uint32_t kLaunchThreads = 768;
+#if defined(MI355_LDS_ADD3)
 constexpr uint32_t kPlaneWords = kTile + kTile / 32 + 8;
+#else
+constexpr uint32_t kPlaneWords = kTile;
+#endif
 // the exchange plane, then a copy of the omega_1280 table (10 KiB): the seams of this shape are table multiplications and their roots
 // come out of LDS (~100 cycles) instead of L2 (several hundred, exposed at every stage)
 constexpr uint32_t kLdsBytes = (kPlaneWords + kM1) * 8;
-__device__ __forceinline__ uint32_t ph(uint32_t i) { return i + (i >> 5); }
+// LDS slot (8 bytes) of tile element i for an exchange: round 4 gives every exchange its own map i ^ ((i >> S) & 31), conflict-free for
+// the lane groups of 64-bit accesses (stores: four groups of 16 lanes on 32 banks, loads: two groups of 32 lanes on 64 banks;
+// MI355X_MICROARCH.md, LDS) in both directions of that exchange.  The single skew i + i / 32 of rounds 2-3 left 44 % of the LDS cycles of
+// these kernels to bank conflicts (SQ_LDS_BANK_CONFLICT 4.03 M of SQ_LDS_IDX_ACTIVE 9.07 M per launch at C4: the last exchange of the front
+// and the first of the back were 4-way conflicted).  -DMI355_LDS_ADD3 restores it for A/B builds.
+template <int S>
+__device__ __forceinline__ uint32_t ph(uint32_t i) {
+#if defined(MI355_LDS_ADD3)
+  return i + (i >> 5);
+#else
+  return i ^ ((i >> S) & 31u);
+#endif
+}
 __device__ __forceinline__ const uint64_t* stage_roots(const DevPlan& pl, uint64_t* X) {
   uint64_t* R = X + kPlaneWords;
   for (uint32_t i = threadIdx.x; i < kM1; i += kThreads) R[i] = pl.UT1[i];
@@ -39,17 +55,17 @@ __device__ __forceinline__ const uint64_t* stage_roots(const DevPlan& pl, uint64
 }
 
 // write 8 (or 10) values to element ids wi[], read ids ri[]; one plane after the other
-template <int NW, int NR, class WI, class RI>
+template <int NW, int NR, int S, class WI, class RI>
 __device__ __forceinline__ void exchange(uint64_t* X, const v2::P2* in, v2::P2* out, bool writer, bool reader, WI wi, RI ri) {
   v2::lds_barrier();
-  if (writer) { _Pragma("unroll") for (int k = 0; k < NW; ++k) X[ph(wi(k))] = in[k].a; }
+  if (writer) { _Pragma("unroll") for (int k = 0; k < NW; ++k) X[ph<S>(wi(k))] = in[k].a; }
   v2::lds_barrier();
   uint64_t ta[NR];
-  if (reader) { _Pragma("unroll") for (int k = 0; k < NR; ++k) ta[k] = X[ph(ri(k))]; }
+  if (reader) { _Pragma("unroll") for (int k = 0; k < NR; ++k) ta[k] = X[ph<S>(ri(k))]; }
   v2::lds_barrier();
-  if (writer) { _Pragma("unroll") for (int k = 0; k < NW; ++k) X[ph(wi(k))] = in[k].b; }
+  if (writer) { _Pragma("unroll") for (int k = 0; k < NW; ++k) X[ph<S>(wi(k))] = in[k].b; }
   v2::lds_barrier();
-  if (reader) { _Pragma("unroll") for (int k = 0; k < NR; ++k) out[k] = {ta[k], X[ph(ri(k))]}; }
+  if (reader) { _Pragma("unroll") for (int k = 0; k < NR; ++k) out[k] = {ta[k], X[ph<S>(ri(k))]}; }
 }
 
 __device__ __forceinline__ void dft5p(v2::P2 (&x)[5], const uint64_t (&c5)[4], bool inverse) {
@@ -107,7 +123,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const 
   }
   // ---- A: DFT5 over d0 ----
   P2 y[10];
-  exchange<8, 10>(X, x, y, true, t < 512,
+  exchange<8, 10, 2>(X, x, y, true, t < 512,
                   [&](int k) { return (t + kThreads * (k >> 2)) * 4 + (k & 3); },
                   [&](int k) { const uint32_t g = t + 512 * (k / 5); return (256 * (k % 5) + (g >> 2)) * 4 + (g & 3); });
   if (t < 512) {
@@ -125,7 +141,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const 
   // ---- B1: DFT4 over e1 ----
   {
     const uint32_t chi = t & 1, e3 = (t >> 1) & 7, e2 = (t >> 4) & 7, k0 = t >> 7;
-    exchange<10, 8>(X, y, x, t < 512, true,
+    exchange<10, 8, 1>(X, y, x, t < 512, true,
                     [&](int k) { const uint32_t g = t + 512 * (k / 5); return ((k % 5) * 256 + (g >> 2)) * 4 + (g & 3); },
                     [&](int k) { return (k0 * 256 + 64 * (k >> 1) + 8 * e2 + e3) * 4 + 2 * chi + (k & 1); });
 #pragma unroll
@@ -142,7 +158,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const 
     // ---- B2: DFT8 over e2 ----
     P2 z[8];
     const uint32_t c = t & 3, f3 = (t >> 2) & 7, f1 = (t >> 5) & 3, f0 = t >> 7;   // reader (k0 | k1 | e3 | c)
-    exchange<8, 8>(X, x, z, true, true,
+    exchange<8, 8, 1>(X, x, z, true, true,
                    [&](int k) { return (((k0 * 4 + (k >> 1)) * 8 + e2) * 8 + e3) * 4 + 2 * chi + (k & 1); },
                    [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; });
     v2::dft8p<false, 1>(z);
@@ -151,7 +167,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const 
     z[0] = {gf::fold(z[0].a), gf::fold(z[0].b)};
     // ---- B3: DFT8 over e3 ----
     const uint32_t g2 = (t >> 2) & 7;   // reader (k0 | k1 | k2 | c): same decode, e3's place holds k2
-    exchange<8, 8>(X, z, x, true, true,
+    exchange<8, 8, 3>(X, z, x, true, true,
                    [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; },
                    [&](int k) { return (((f0 * 4 + f1) * 8 + g2) * 8 + k) * 4 + c; });
     v2::dft8p<false, 2>(x);
@@ -193,7 +209,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const 
     for (int j = 0; j < 8; ++j) { x[j] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)}; if (j < 7) ca = gf::mul(ca, B); }
   }
   v2::dft8p<true, 2>(x);   // k3 -> e3; multiplied by the seam next
-  exchange<8, 8>(X, x, z, true, true,
+  exchange<8, 8, 3>(X, x, z, true, true,
                  [&](int k) { return (((f0 * 4 + f1) * 8 + g2) * 8 + k) * 4 + c; },
                  [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; });
 #pragma unroll
@@ -201,7 +217,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const 
   z[0] = {gf::fold(z[0].a), gf::fold(z[0].b)};
   v2::dft8p<true, 2>(z);   // k2 -> e2
   const uint32_t chi = t & 1, e3 = (t >> 1) & 7, e2 = (t >> 4) & 7, k0 = t >> 7;
-  exchange<8, 8>(X, z, x, true, true,
+  exchange<8, 8, 1>(X, z, x, true, true,
                  [&](int k) { return (((f0 * 4 + f1) * 8 + k) * 8 + f3) * 4 + c; },
                  [&](int k) { return (((k0 * 4 + (k >> 1)) * 8 + e2) * 8 + e3) * 4 + 2 * chi + (k & 1); });
   {
@@ -220,7 +236,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const 
     }
   }
   P2 y[10];
-  exchange<8, 10>(X, x, y, true, t < 512,
+  exchange<8, 10, 1>(X, x, y, true, t < 512,
                   [&](int k) { return (k0 * 256 + 64 * (k >> 1) + 8 * e2 + e3) * 4 + 2 * chi + (k & 1); },
                   [&](int k) { const uint32_t g = t + 512 * (k / 5); return ((k % 5) * 256 + (g >> 2)) * 4 + (g & 3); });
   if (t < 512) {
@@ -235,7 +251,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const 
       for (int d0 = 0; d0 < 5; ++d0) y[5 * q + d0] = w5[d0];
     }
   }
-  exchange<10, 8>(X, y, x, t < 512, true,
+  exchange<10, 8, 2>(X, y, x, t < 512, true,
                   [&](int k) { const uint32_t g = t + 512 * (k / 5); return (256 * (k % 5) + (g >> 2)) * 4 + (g & 3); },
                   [&](int k) { return (t + kThreads * (k >> 2)) * 4 + (k & 3); });
   // ---- unweight, x a, carry along the thread's two runs ----
