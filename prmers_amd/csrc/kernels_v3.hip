@@ -187,6 +187,145 @@ __global__ void __launch_bounds__(kThreads) k2_rows1024(DevPlan pl, const uint64
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same rows with ONE PLANE per thread (512 threads: lane 2 t + plane, the two words of a pair go through identical, independent
+// arithmetic): where a CU gets a single row (M1 < 512: C2, n = 2^18) the launch lasts as long as one wave's dependent stream, and two waves
+// per SIMD with half the stream each are shorter than one.  Same stages, maps and table words as k2_rows1024; LDS slots are 8 bytes
+// (2 map(i) + plane); the pointwise stage meets its partner plane through a DPP lane swap (quad_perm 1,0,3,2): every lane computes its
+// own square / product, the product by rho travels from the b lane to the a lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t swap_planes(uint64_t v) {
+  const uint32_t lo = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(v)), 0xB1, 0xF, 0xF, false));
+  const uint32_t hi = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(v >> 32)), 0xB1, 0xF, 0xF, false));
+  return (uint64_t(hi) << 32) | lo;
+}
+template <bool INV>
+__device__ __forceinline__ void dft4w(uint64_t (&x)[4]) { v2::dft4<INV>(x[0], x[1], x[2], x[3]); }
+__device__ __forceinline__ void twiddle3w(uint64_t (&x)[4], const uint64_t (&w)[3]) {
+#pragma unroll
+  for (int k = 1; k < 4; ++k) x[k] = gf::mul(x[k], w[k - 1]);
+}
+#define V3_EXCHW(X, x, pln, WIDX, RIDX)                                              \
+  lds_barrier();                                                                     \
+  _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) X[2 * (WIDX(k_)) + pln] = x[k_];  \
+  lds_barrier();                                                                     \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) x[j_] = X[2 * (RIDX(j_)) + pln];
+
+template <int mode>
+__global__ void __launch_bounds__(2 * kThreads) k2_rows1024_planes(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
+                                                                   uint64_t* __restrict__ Wout, uint32_t sub) {
+  uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
+  const uint32_t t = threadIdx.x >> 1, pln = threadIdx.x & 1u, row = blockIdx.x;
+  const uint64_t* in = Win + size_t(row) * 2048;
+  uint64_t* out = Wout + size_t(row) * 2048;
+  const uint64_t* __restrict__ UT = pl.UT2;
+  uint64_t x[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = in[2 * (256 * j + t) + pln];
+  uint64_t w1[3], w2[3], w3[3], w4[3], v1[3], v2w[3], v3w[3], v4[3];
+#pragma unroll
+  for (uint32_t k = 1; k < 4; ++k) {
+    const uint32_t e1 = k * t, e2 = 4 * k * (t & 63u), e3 = 16 * k * (t & 15u), e4 = 64 * k * (t & 3u);
+    w1[k - 1] = UT[e1]; w2[k - 1] = UT[e2]; w3[k - 1] = UT[e3]; w4[k - 1] = UT[e4];
+    if (mode != 2) {
+      v1[k - 1] = UT[(1024 - e1) & 1023]; v2w[k - 1] = UT[(1024 - e2) & 1023]; v3w[k - 1] = UT[(1024 - e3) & 1023]; v4[k - 1] = UT[(1024 - e4) & 1023];
+    }
+  }
+  const uint32_t kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t) + 64 * (t & 3u);
+  const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;
+  const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * kb;
+  uint64_t rho_lo = 0, rho_hi = 0;
+  if (mode != 2) { rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)]; rho_hi = pl.TWhi[erho >> pl.twh]; }
+  if (sub != 0 && threadIdx.x == 0) x[0] = gf::sub(x[0], uint64_t(sub));   // element 0, plane a
+
+  // ---- forward ----
+  dft4w<false>(x); twiddle3w(x, w1);
+#define WI(k) idx_a(t, k)
+#define RI(j) idx_b(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w2);
+#define WI(k) idx_b(t, k)
+#define RI(j) idx_c(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w3);
+#define WI(k) m2(idx_c(t, k))
+#define RI(j) m2(idx_d(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w4);
+#define WI(k) m2(idx_d(t, k))
+#define RI(j) m2(idx_e(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x);
+
+  if (mode == 2) {   // the image: the layout of k2_rows1024 (register j of thread t at pair 256 j + t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[2 * (256 * j + t) + pln] = x[j];
+    return;
+  }
+
+  // ---- pointwise: lane a holds u.a, lane b holds u.b of X[kb + 256 k5]; rho = rho0 {1, 2^48, -1, -2^48} ----
+  {
+    const uint64_t rho0 = gf::mul(rho_lo, rho_hi);
+    const uint64_t* Y = Yimg + size_t(row) * 2048;
+#pragma unroll
+    for (int k5 = 0; k5 < 4; ++k5) {
+      const uint64_t u = x[k5], uo = swap_planes(u);
+      uint64_t m1, cross;
+      if (mode == 0) {   // (u0 + u1 t)^2 mod (t^2 - rho), marin.cl:379-384
+        m1 = gf::sqr(u);                      // a: u.a^2, b: u.b^2
+        cross = gf::dbl(gf::mul(u, uo));      // 2 u.a u.b (both lanes)
+      } else {           // marin.cl:387-392
+        const uint64_t y = Y[2 * (256 * k5 + t) + pln], yo = swap_planes(y);
+        m1 = gf::mul(u, y);                   // a: u.a y.a, b: u.b y.b
+        const uint64_t m3 = gf::mul(u, yo);   // a: u.a y.b, b: u.b y.a
+        cross = gf::add(m3, swap_planes(m3));
+      }
+      uint64_t q = swap_planes(gf::mul(m1, rho0));   // lane a receives u.b^2 rho0 (u.b y.b rho0)
+      if (k5 & 1) q = gf::mul_pow2(q, 48);
+      const uint64_t ra = (k5 & 2) ? gf::sub(m1, q) : gf::add(m1, q);
+      x[k5] = pln ? cross : ra;
+    }
+  }
+
+  // ---- inverse (mirror) ----
+  dft4w<true>(x);
+#define WI(k) m2(idx_e(t, k))
+#define RI(j) m2(idx_d(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v4); dft4w<true>(x);
+#define WI(k) m2(idx_d(t, k))
+#define RI(j) m2(idx_c(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v3w); dft4w<true>(x);
+#define WI(k) idx_c(t, k)
+#define RI(j) idx_b(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v2w); dft4w<true>(x);
+#define WI(k) idx_b(t, k)
+#define RI(j) idx_a(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v1); dft4w<true>(x);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[2 * (256 * j + t) + pln] = x[j];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column tiles, M1 = 256 = 4.4.4.4 with C = 4 pairs per run (tile = 1024 pairs).  Tile element (i1, c), i1 = 64 d1 + 16 d2 + 4 d3 + d4,
 // tile index 4 i1 + c (five base-4 digits d1 | d2 | d3 | d4 | c).
 // front (digits -> work buffer):
@@ -358,6 +497,175 @@ __global__ void __launch_bounds__(kThreads) k3_cols256(DevPlan pl, const uint64_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The column kernels with one plane per thread (512 threads, lane 2 t + plane): plane a = the even digits of the run, plane b the odd ones.
+// Same stages, maps and tables as k1_cols256 / k3_cols256; both lanes of a pair load the run and compute its carry-in / carry chain (a few
+// integer instructions), each weights, transforms and twiddles its own plane; the back sweep meets the partner plane through a DPP lane swap
+// before the carry.  Chosen where the launch is a single round of tiles (one wave per SIMD otherwise): shorter dependent stream per wave.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(2 * kThreads) k1_cols256_planes(DevPlan pl, const uint32_t* __restrict__ digits, const uint64_t* __restrict__ cbuf_in, uint32_t sub,
+                                                                  uint64_t* __restrict__ Wout) {
+  uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
+  const uint32_t t = threadIdx.x >> 1, pln = threadIdx.x & 1u, T = blockIdx.x;
+  const uint64_t* __restrict__ UT = pl.UT1;
+  uint64_t w1[3], w2[3], w3[3];
+#pragma unroll
+  for (uint32_t k = 1; k < 4; ++k) { w1[k - 1] = UT[k * (t >> 2)]; w2[k - 1] = UT[4 * k * ((t >> 2) & 15u)]; w3[k - 1] = UT[16 * k * ((t >> 2) & 3u)]; }
+  const uint32_t c4 = t & 3u, kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t), i2 = 4 * T + c4;
+  const uint64_t fca0 = pl.F0f[size_t(T) * kThreads + t], fB = pl.FBf[i2];
+  const uint32_t di = pl.DI[size_t(T) * kThreads + t];
+  const uint64_t tah = gf::half(pl.TA[256 * pln + t]);   // odd digits: the second half of TA (plan.hpp)
+  uint32_t dg[8];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * 256 + t) * 2;
+    const uint4 a = src[0], b = src[1];
+    dg[0] = a.x; dg[1] = a.y; dg[2] = a.z; dg[3] = a.w; dg[4] = b.x; dg[5] = b.y; dg[6] = b.z; dg[7] = b.w;
+  }
+  if (cbuf_in) v2::apply_carry_in<8>(pl, di, 0, v2::carry_in_of(pl, cbuf_in, T, t), dg);
+  uint64_t x[4];
+  const uint32_t nowrap = ~di;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    // (a select between two elements of dg would be turned into a run-time index and put the array into scratch: mask arithmetic instead)
+    const uint32_t d = dg[2 * c] ^ ((dg[2 * c] ^ dg[2 * c + 1]) & (0u - pln));
+    const uint32_t sh = nowrap >> (4 * c + 1 + 2 * pln);
+    x[c] = gf::mul_u32(tah, d << (sh & 1u));
+  }
+  if (sub != 0 && T == 0 && threadIdx.x == 0) x[0] = gf::sub(x[0], uint64_t(sub));   // digit 0 has weight 1
+#define WI(k) m2(idx_e(t, k))
+#define RI(j) m2(idx_a(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w1);
+#define WI(k) idx_a(t, k)
+#define RI(j) idx_b(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w2);
+#define WI(k) idx_b(t, k)
+#define RI(j) idx_c(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w3);
+#define WI(k) m2(idx_c(t, k))
+#define RI(j) m2(idx_d(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x);
+  {
+    uint64_t ca = fca0;
+    const uint32_t row0 = __brev(kb) >> 24;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Wout[2 * (size_t(row0 + rev2(j)) * pl.M2 + i2) + pln] = gf::mul(x[j], ca);
+      if (j < 3) ca = gf::mul(ca, fB);
+    }
+  }
+}
+
+template <bool EXT>
+__global__ void __launch_bounds__(2 * kThreads) k3_cols256_planes(DevPlan pl, const uint64_t* __restrict__ Win, uint32_t* __restrict__ digits,
+                                                                  uint64_t* __restrict__ cbuf, uint32_t a, uint64_t scale, BackExt ext) {
+  uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
+  const uint32_t t = threadIdx.x >> 1, pln = threadIdx.x & 1u, T = v2::tile_of_block(pl, blockIdx.x, gridDim.x);
+  const uint64_t* __restrict__ UT = pl.UT1;
+  uint64_t v1[3], v2w[3], v3w[3];
+#pragma unroll
+  for (uint32_t k = 1; k < 4; ++k) {
+    v1[k - 1] = UT[(256 - k * (t >> 2)) & 255]; v2w[k - 1] = UT[(256 - 4 * k * ((t >> 2) & 15u)) & 255]; v3w[k - 1] = UT[(256 - 16 * k * ((t >> 2) & 3u)) & 255];
+  }
+  const uint32_t c4 = t & 3u, kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t), i2 = 4 * T + c4;
+  const uint32_t di = pl.DI[size_t(T) * kThreads + t];
+  const uint64_t tai = pl.TAi[256 * pln + t];
+  uint32_t ad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (EXT && ext.add_digits) {
+    const uint4* src = reinterpret_cast<const uint4*>(ext.add_digits) + (size_t(T) * 256 + t) * 2;
+    const uint4 p = src[0], q = src[1];
+    ad[0] = p.x; ad[1] = p.y; ad[2] = p.z; ad[3] = p.w; ad[4] = q.x; ad[5] = q.y; ad[6] = q.z; ad[7] = q.w;
+    if (ext.add_cbuf) v2::apply_carry_in<8>(pl, di, 0, v2::carry_in_of(pl, ext.add_cbuf, T, t), ad);
+  }
+  uint64_t x[4];
+  {
+    uint64_t ca = pl.F0i[size_t(T) * kThreads + t];
+    const uint64_t B = pl.FBi[i2];
+    if (scale != 1) ca = gf::mul(ca, scale);
+    const uint32_t row0 = __brev(kb) >> 24;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = Win[2 * (size_t(row0 + rev2(j)) * pl.M2 + i2) + pln];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = gf::mul(x[j], ca);
+      if (j < 3) ca = gf::mul(ca, B);
+    }
+  }
+  dft4w<true>(x);
+#define WI(k) m2(idx_d(t, k))
+#define RI(j) m2(idx_c(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v3w); dft4w<true>(x);
+#define WI(k) idx_c(t, k)
+#define RI(j) idx_b(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v2w); dft4w<true>(x);
+#define WI(k) idx_b(t, k)
+#define RI(j) idx_a(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v1); dft4w<true>(x);
+#define WI(k) m2(idx_a(t, k))
+#define RI(j) m2(idx_e(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  // unweight this lane's plane (digit 2 c + plane of the run i1 = t), then both lanes take the partner's four values and run the carry
+  const uint64_t tai2 = gf::dbl(tai);
+  uint64_t own[4], oth[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool wrap = ((di >> (2 * (2 * c + int(pln)))) & 2u) != 0;   // digit-info table: width - q, wrap
+    own[c] = gf::mul(x[c], wrap ? tai2 : tai);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) oth[c] = swap_planes(own[c]);
+  uint64_t carry = 0;
+  uint32_t dg[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t bits = di >> (2 * k);
+    const uint32_t width = pl.q + (bits & 1u);
+    const uint64_t u = ((k & 1) == int(pln)) ? own[k >> 1] : oth[k >> 1];
+    const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
+    if (a == 1) {
+      const uint64_t r = u + carry + (EXT ? ad[k] : 0u);
+      dg[k] = __builtin_amdgcn_ubfe(uint32_t(r), 0u, width);
+      carry = r >> width;
+    } else {
+      const uint64_t dlo = u & mask, chi = u >> width;
+      const uint64_t r = dlo * a + carry + (EXT ? ad[k] : 0u);
+      dg[k] = uint32_t(r & mask);
+      carry = (r >> width) + chi * a;
+    }
+  }
+  // lane a stores the first four digits (and the carry word), lane b the last four
+  uint4* dst = reinterpret_cast<uint4*>(digits) + (size_t(T) * 256 + t) * 2;
+  dst[pln] = pln ? make_uint4(dg[4], dg[5], dg[6], dg[7]) : make_uint4(dg[0], dg[1], dg[2], dg[3]);
+  if (!pln) cbuf[size_t(T) * 256 + t] = carry;
+  if (EXT && ext.digits2) {
+    uint4* d2 = reinterpret_cast<uint4*>(ext.digits2) + (size_t(T) * 256 + t) * 2;
+    d2[pln] = pln ? make_uint4(dg[4], dg[5], dg[6], dg[7]) : make_uint4(dg[0], dg[1], dg[2], dg[3]);
+    if (!pln) ext.cbuf2[size_t(T) * 256 + t] = carry;
+  }
+}
+
 // chain starts and ratios of the four-step twiddle chains (same thread map as the last stage of k1_cols256 / first stage of k3_cols256):
 // F0f[T][t] = omega_m^(i2 kb) TB[2 i2], F0i the inverse with TBi, FBf[i2] = omega_m^(64 i2), FBi its inverse
 __global__ void __launch_bounds__(kThreads) k_build_f0(DevPlan pl, uint64_t* __restrict__ f0f, uint64_t* __restrict__ f0i, uint64_t* __restrict__ fbf,
@@ -378,11 +686,11 @@ __global__ void __launch_bounds__(kThreads) k_build_f0(DevPlan pl, uint64_t* __r
 
 // ------------------------------- shapes and launch wrappers -----------------------------------
 // MI355_TUNE bit 7 switches the set off (A/B runs against the generic kernels).
-// Rows: only where a CU gets at least two of them (M1 >= 512).  With one row per CU the launch lasts as long as one wave's dependent
-// stream, and the generic row kernel -- sixteen waves per row, one plane of a butterfly per thread -- is the shorter one: C2 rows 10.6 us
-// against 12.8 us here, n = 2^18 10.8 against 12.5 (same-box A/B, profiles/r04_ab_radix4_set.txt); with five rows per CU (n = 5 2^19)
-// this kernel's lower instruction count wins, 26.0 against 30.1 us.  Bit 8 forces the rows at any M1 (tests, A/B).
-bool v3_rows_shape(const DevPlan& pl) { return pl.M2 == 1024 && !(pl.tune & 128) && (pl.M1 >= 512 || (pl.tune & 256)); }
+// Rows: with one row per CU the launch lasts as long as one wave's dependent stream: the pair-per-thread kernel (one wave per SIMD) takes
+// 12.8 us at C2 against 10.6 us for the generic rows (eight waves per row, one plane of a butterfly per thread); the plane-per-thread form
+// below serves those sizes; with five rows per CU (n = 5 2^19) the pair form's lower instruction count wins, 26.0 against 30.1 us
+// (same-box A/B, profiles/r04_ab_radix4_set.txt).
+bool v3_rows_shape(const DevPlan& pl) { return pl.M2 == 1024 && !(pl.tune & 128); }
 bool v3_cols_shape(const DevPlan& pl) { return pl.r5 == 1 && pl.M1 == 256 && pl.C == 4 && pl.M2 >= 8 && pl.DI != nullptr && !(pl.tune & 128); }
 size_t v3_threads_per_tile() { return v3::kThreads; }
 
@@ -392,6 +700,18 @@ hipError_t v3_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 }
 hipError_t v3_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
   const dim3 grid(pl.M1), block(v3::kThreads);
+  // one row per CU or fewer: one plane per thread (twice the waves, half the stream each); more rows: a pair per thread (fewer
+  // instructions per word).  MI355_TUNE bit 8 forces the pair form, bit 9 the plane form (A/B runs).
+  const bool planes = ((pl.M1 < 512) && !(pl.tune & 256)) || (pl.tune & 512);
+  if (planes) {
+    const dim3 block2(2 * v3::kThreads);
+    switch (mode) {
+      case 0: hipLaunchKernelGGL(v3::k2_rows1024_planes<0>, grid, block2, v3::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
+      case 1: hipLaunchKernelGGL(v3::k2_rows1024_planes<1>, grid, block2, v3::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
+      default: hipLaunchKernelGGL(v3::k2_rows1024_planes<2>, grid, block2, v3::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
+    }
+    return hipGetLastError();
+  }
   switch (mode) {
     case 0: hipLaunchKernelGGL(v3::k2_rows1024<0>, grid, block, v3::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
     case 1: hipLaunchKernelGGL(v3::k2_rows1024<1>, grid, block, v3::kLdsBytes, s, pl, Win, Y, Wout, sub); break;
@@ -399,16 +719,21 @@ hipError_t v3_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
   }
   return hipGetLastError();
 }
+// columns: one plane per thread where the tiles make a single round (at most two per CU; MI355_TUNE bit 10 forces the pair form, bit 11 the plane form)
+static bool cols_planes(const DevPlan& pl) { return ((pl.M2 / 4 <= 512) && !(pl.tune & 1024)) || (pl.tune & 2048); }
 hipError_t v3_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
-  hipLaunchKernelGGL(v3::k1_cols256, dim3(pl.M2 / 4), dim3(v3::kThreads), v3::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
+  if (cols_planes(pl)) hipLaunchKernelGGL(v3::k1_cols256_planes, dim3(pl.M2 / 4), dim3(2 * v3::kThreads), v3::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
+  else hipLaunchKernelGGL(v3::k1_cols256, dim3(pl.M2 / 4), dim3(v3::kThreads), v3::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
   return hipGetLastError();
 }
 hipError_t v3_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s) {
-  hipLaunchKernelGGL(v3::k3_cols256<false>, dim3(pl.M2 / 4), dim3(v3::kThreads), v3::kLdsBytes, s, pl, W, digits, cbuf, a, scale, BackExt());
+  if (cols_planes(pl)) hipLaunchKernelGGL(v3::k3_cols256_planes<false>, dim3(pl.M2 / 4), dim3(2 * v3::kThreads), v3::kLdsBytes, s, pl, W, digits, cbuf, a, scale, BackExt());
+  else hipLaunchKernelGGL(v3::k3_cols256<false>, dim3(pl.M2 / 4), dim3(v3::kThreads), v3::kLdsBytes, s, pl, W, digits, cbuf, a, scale, BackExt());
   return hipGetLastError();
 }
 hipError_t v3_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s) {
-  hipLaunchKernelGGL(v3::k3_cols256<true>, dim3(pl.M2 / 4), dim3(v3::kThreads), v3::kLdsBytes, s, pl, W, digits, cbuf, a, uint64_t(1), x);
+  if (cols_planes(pl)) hipLaunchKernelGGL(v3::k3_cols256_planes<true>, dim3(pl.M2 / 4), dim3(2 * v3::kThreads), v3::kLdsBytes, s, pl, W, digits, cbuf, a, uint64_t(1), x);
+  else hipLaunchKernelGGL(v3::k3_cols256<true>, dim3(pl.M2 / 4), dim3(v3::kThreads), v3::kLdsBytes, s, pl, W, digits, cbuf, a, uint64_t(1), x);
   return hipGetLastError();
 }
 
