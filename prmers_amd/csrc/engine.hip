@@ -119,6 +119,14 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
       HIPCHK(hipStreamSynchronize(stream_));
       dp_.F0f = f0_; dp_.F0i = f0_ + nt; dp_.FBf = f0_ + 2 * nt; dp_.FBi = f0_ + 2 * nt + pl_.M2;
     }
+#if defined(MI355_EXPERIMENTAL)
+    if (v2rows_ && v2cols_) chain_tiles_ = v3_chain_tiles(dp_, device_);
+    if (chain_tiles_) {
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&chain_x_), size_t(chain_tiles_) * 256 * 8));
+      HIPCHK(hipMalloc(reinterpret_cast<void**>(&chain_flags_), (size_t(chain_tiles_) + 1) * 4));
+      HIPCHK(hipMemsetAsync(chain_flags_, 0, (size_t(chain_tiles_) + 1) * 4, stream_));
+    }
+#endif
   }
 
 #if defined(MI355_EXPERIMENTAL)
@@ -163,6 +171,10 @@ Engine::~Engine() {
   if (split_) (void)hipFree(split_);
   if (canon_) (void)hipFree(canon_);
 #if defined(MI355_EXPERIMENTAL)
+  if (chain_x_) (void)hipFree(chain_x_);
+  if (chain_flags_) (void)hipFree(chain_flags_);
+#endif
+#if defined(MI355_EXPERIMENTAL)
   if (coop_flags_) (void)hipFree(coop_flags_);
 #endif
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -180,7 +192,22 @@ void Engine::sync() {
   HIPCHK(hipSetDevice(device_));
   HIPCHK(hipStreamSynchronize(stream_));
   coop_check();
+  chain_check();
 }
+
+#if defined(MI355_EXPERIMENTAL)
+// The fused back + front launches of square_mul_n hand carry words from tile to tile inside the launch; a wait that timed out raised the
+// error word and left garbage behind: nothing is read out of the engine after that.
+void Engine::chain_check() {
+  if (chain_failed_) throw std::runtime_error("chained squaring kernel: a carry hand-over timed out earlier; the engine's registers are not valid");
+  if (!chain_used_) return;
+  uint32_t err = 0;
+  HIPCHK(hipMemcpyAsync(&err, chain_flags_ + chain_tiles_, 4, hipMemcpyDeviceToHost, stream_));
+  HIPCHK(hipStreamSynchronize(stream_));
+  chain_used_ = false;
+  if (err) { chain_failed_ = true; throw std::runtime_error("chained squaring kernel: carry hand-over timed out (tiles not co-resident?)"); }
+}
+#endif
 
 #if defined(MI355_EXPERIMENTAL)
 // The grid barrier of k_coop gives up after 0.2 s and raises the error word; the results of that launch are garbage.
@@ -298,6 +325,7 @@ uint32_t* Engine::canon_digits(size_t r, int slot) {
   need_digits(r, "get");
   HIPCHK(hipSetDevice(device_));
   coop_check();   // nothing is read out of an engine whose one-launch kernel gave up at a grid barrier
+  chain_check();
   const size_t sw = canon_scratch_words(dp_);
   if (!canon_) {
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&canon_), (sw + 2 * pl_.n) * 4));
@@ -338,6 +366,7 @@ void Engine::read_values_host(size_t src, std::vector<uint64_t>& v) {
   stage_.resize(pl_.n);
   HIPCHK(hipSetDevice(device_));
   coop_check();
+  chain_check();
   normalize(src);
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(stage_.data(), digits(src), pl_.n * 4, hipMemcpyDeviceToHost));
@@ -549,6 +578,26 @@ void Engine::square_mul_n(size_t r, uint32_t a, size_t count, uint32_t sub) {
 #if defined(MI355_EXPERIMENTAL)
   if (coop_groups_ && pending_sub_[r] < (1u << 30) && sub < (1u << 30)) { coop_launch(r, a, count, sub); return; }
 #endif
+#if defined(MI355_EXPERIMENTAL)
+  if (chain_tiles_ && count >= 2 && sub < (1u << 30) && !chain_failed_) {
+    // front | rows | [back + front | rows] x (count - 1) | back: the back sweep of a squaring and the front sweep of the next one are ONE
+    // launch on the small shapes (kernels_v3.hip k31_cols256_planes); same digits as the loop below
+    run_front(r);                                      // consumes pending carries / subtraction
+    for (size_t i = 0; i + 1 < count; ++i) {
+      run_middle(work(), nullptr, work(), 0, 0);
+      HIPCHK(v3_launch_backfront(dp_, work(), a, sub, chain_x_, chain_flags_, ++chain_epoch_, stream_));
+      chain_used_ = true;
+      if (chain_epoch_ >= 0x7fff0000u) {               // the flags compare epochs in 31 bits: start over
+        HIPCHK(hipMemsetAsync(chain_flags_, 0, size_t(chain_tiles_) * 4, stream_));
+        chain_epoch_ = 0;
+      }
+    }
+    run_middle(work(), nullptr, work(), 0, 0);
+    run_back(r, a);
+    if (sub) sub_u32(r, sub);
+    return;
+  }
+#endif
   for (size_t i = 0; i < count; ++i) { square_chain(r, a, nullptr); if (sub) sub_u32(r, sub); }
 }
 
@@ -712,6 +761,7 @@ void Engine::get_data(size_t src, void* data, size_t size) {
   if (size != register_data_size()) throw std::runtime_error("get_data: size mismatch");
   HIPCHK(hipSetDevice(device_));
   coop_check();
+  chain_check();
   normalize(src);
   HIPCHK(hipStreamSynchronize(stream_));
   HIPCHK(hipMemcpy(data, slot_[src], reg_bytes_, hipMemcpyDeviceToHost));
@@ -780,6 +830,10 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
   } else
 #endif
   {
+#if defined(MI355_EXPERIMENTAL)
+    if (chain_tiles_) square_mul_n(r, a, iters, sub);   // the run of squarings as the callers issue it (back + front in one launch on the small shapes)
+    else
+#endif
     for (size_t i = 0; i < iters; ++i) {
       square_chain(r, a, nullptr);
       if (sub) sub_u32(r, sub);

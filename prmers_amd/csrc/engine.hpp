@@ -129,6 +129,17 @@ class Engine {
   std::vector<uint8_t> pending_carry_;   // cbuf(r) not yet folded into the digits
   std::vector<uint32_t> pending_sub_;    // small constant still to subtract (LL's -2)
   bool v2rows_ = false, v2cols_ = false;
+#if defined(MI355_EXPERIMENTAL)
+  // runs of squarings with back + front in one launch (kernels_v3.hip k31_cols256_planes; square_mul_n): tiles of such a launch (0: not
+  // served), carry hand-over words, flag words (+ the error word), epochs used so far, whether a launch is still unchecked / has failed
+  uint32_t chain_tiles_ = 0, chain_epoch_ = 0;
+  uint64_t* chain_x_ = nullptr;
+  uint32_t* chain_flags_ = nullptr;
+  bool chain_used_ = false, chain_failed_ = false;
+  void chain_check();   // throws when a hand-over wait of an earlier launch timed out (the registers are not valid then)
+#else
+  void chain_check() {}
+#endif
   std::vector<uint8_t> width_;   // natural order
   std::vector<uint32_t> stage_;  // host staging (one register of digits)
   uint32_t* canon_ = nullptr;    // device scratch of the canonicalisation: work arrays + two outputs of n digits (lazy)

@@ -75,6 +75,13 @@ hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s);
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s);
+#if defined(MI355_EXPERIMENTAL)
+// runs of squarings on the small shapes (kernels_v3.hip): the back sweep of one squaring and the front sweep of the next in one launch.
+// v3_chain_tiles: tiles of such a launch (all resident at once on `device`), 0 where the plan is not served.  xbuf: tiles x 256 carry
+// words, flags: tiles + 1 words (the last one is the error word a timed-out wait raises), epoch: larger than any used before on these flags
+uint32_t v3_chain_tiles(const DevPlan& pl, int device);
+hipError_t v3_launch_backfront(const DevPlan& pl, uint64_t* W, uint32_t a, uint32_t sub, uint64_t* xbuf, uint32_t* flags, uint32_t epoch, hipStream_t s);
+#endif
 #if defined(MI355_PROBE)
 size_t v2_lds_bytes();
 // one launch of sweep `kind` (0 front, 1 rows, 2 back) over grid_mult x the normal grid with extra_lds bytes of padding LDS

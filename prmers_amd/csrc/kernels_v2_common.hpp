@@ -211,5 +211,10 @@ hipError_t v3_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
 hipError_t v3_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
 hipError_t v3_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s);
 hipError_t v3_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, const BackExt& x, hipStream_t s);
+#if defined(MI355_EXPERIMENTAL)
+// back sweep of one squaring + front sweep of the next in one launch (kernels_v3.hip k31_cols256_planes): tiles served (0: not), launch
+uint32_t v3_chain_tiles(const DevPlan& pl, int device);
+hipError_t v3_launch_backfront(const DevPlan& pl, uint64_t* W, uint32_t a, uint32_t sub, uint64_t* xbuf, uint32_t* flags, uint32_t epoch, hipStream_t s);
+#endif
 
 }  // namespace mi355

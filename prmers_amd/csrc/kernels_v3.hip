@@ -666,6 +666,178 @@ __global__ void __launch_bounds__(2 * kThreads) k3_cols256_planes(DevPlan pl, co
   }
 }
 
+#if defined(MI355_EXPERIMENTAL)
+// ---------------------------------------------------------------------------------------------
+// Back sweep of squaring i and front sweep of squaring i + 1 in ONE launch (plane-per-thread form), for the shapes whose tiles are all
+// resident at once (C2: 256 tiles, n = 2^20: 512; Engine::square_mul_n runs front | rows | [this | rows] x (count - 1) | back).
+// Everything between the two sweeps is local to a tile -- the thread that ends the back sweep with the eight digits of run i1 = t is the
+// thread that starts the front sweep with them, so the digits never leave their registers -- except the carry word of the PREVIOUS run in
+// digit order, which the neighbouring tile produces (reference: carry_weight_mul_p1 / p2 hand it through a carry array and a second
+// kernel, kernels/marin.cl:1696-1728,2198-2216).  Hand-over inside the launch: every group stores its 256 carry words with agent-scope
+// stores (past the XCD's non-coherent L2), drains them (s_waitcnt vmcnt(0)), publishes an epoch in its flag word, then waits for the flag
+// of the one tile it depends on and reads that tile's words with agent-scope loads.  A carry-out depends only on the tile's own data, so
+// there is no cycle; tiles are taken in block order, so the tile waited for is resident or done (see the kernel's first lines).
+// A wait that outlasts kChainTimeoutTicks (100 MHz clock: 50 ms) raises the error word -- the engine refuses every later read-out -- and
+// goes on, so that the grid always drains.  MEASURED: C2 0.0265 -> 0.0259 ms (-2 %), n = 2^20 no change (profiles/r04_ab_chain_backfront.txt):
+// the hand-over costs what the kernel boundary it replaces costs.  Kept out of the product library for that (inter-group waits for 2 %):
+// built only with -DMI355_EXPERIMENTAL (make exp), parity-tested there (tools/exp_coop_check.py).
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kChainTimeoutTicks = 5000000ull;
+
+__global__ void __launch_bounds__(2 * kThreads) k31_cols256_planes(DevPlan pl, uint64_t* __restrict__ Wbuf, uint32_t a, uint32_t sub, uint64_t* __restrict__ xbuf,
+                                                                   uint32_t* __restrict__ flags, uint32_t* __restrict__ err, uint32_t epoch) {
+  uint64_t* X = reinterpret_cast<uint64_t*>(v2::smem_v2);
+  __shared__ uint32_t wait_ok;
+  // Tile = block index, in plain order: a group waits for its predecessor tile only, work-groups are dispatched in ascending order, so the
+  // group waited for is resident or done whatever else shares the GPU (only tile 0 waits for the last tile, which every other group's
+  // progress brings in): no dead-lock even when the launch is not resident as a whole.
+  const uint32_t t = threadIdx.x >> 1, pln = threadIdx.x & 1u, T = blockIdx.x, NT = gridDim.x;
+  const uint64_t* __restrict__ UT = pl.UT1;
+  uint64_t v1[3], v2w[3], v3w[3], w1[3], w2[3], w3[3];
+#pragma unroll
+  for (uint32_t k = 1; k < 4; ++k) {
+    const uint32_t e1 = k * (t >> 2), e2 = 4 * k * ((t >> 2) & 15u), e3 = 16 * k * ((t >> 2) & 3u);
+    v1[k - 1] = UT[(256 - e1) & 255]; v2w[k - 1] = UT[(256 - e2) & 255]; v3w[k - 1] = UT[(256 - e3) & 255];
+    w1[k - 1] = UT[e1]; w2[k - 1] = UT[e2]; w3[k - 1] = UT[e3];
+  }
+  const uint32_t c4 = t & 3u, kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t), i2 = 4 * T + c4;
+  const uint32_t di = pl.DI[size_t(T) * kThreads + t];
+  const uint64_t tai = pl.TAi[256 * pln + t], tah = gf::half(pl.TA[256 * pln + t]);
+  const uint64_t fca0 = pl.F0f[size_t(T) * kThreads + t], fB = pl.FBf[i2];
+  const uint32_t row0 = __brev(kb) >> 24;
+  // ---- back sweep of the tile (k3_cols256_planes) ----
+  uint64_t x[4];
+  {
+    uint64_t ca = pl.F0i[size_t(T) * kThreads + t];
+    const uint64_t B = pl.FBi[i2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = Wbuf[2 * (size_t(row0 + rev2(j)) * pl.M2 + i2) + pln];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = gf::mul(x[j], ca);
+      if (j < 3) ca = gf::mul(ca, B);
+    }
+  }
+  dft4w<true>(x);
+#define WI(k) m2(idx_d(t, k))
+#define RI(j) m2(idx_c(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v3w); dft4w<true>(x);
+#define WI(k) idx_c(t, k)
+#define RI(j) idx_b(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v2w); dft4w<true>(x);
+#define WI(k) idx_b(t, k)
+#define RI(j) idx_a(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  twiddle3w(x, v1); dft4w<true>(x);
+#define WI(k) m2(idx_a(t, k))
+#define RI(j) m2(idx_e(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  const uint64_t tai2 = gf::dbl(tai);
+  uint64_t own[4], oth[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool wrap = ((di >> (2 * (2 * c + int(pln)))) & 2u) != 0;
+    own[c] = gf::mul(x[c], wrap ? tai2 : tai);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) oth[c] = swap_planes(own[c]);
+  uint64_t carry = 0;
+  uint32_t dg[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t bits = di >> (2 * k);
+    const uint32_t width = pl.q + (bits & 1u);
+    const uint64_t u = ((k & 1) == int(pln)) ? own[k >> 1] : oth[k >> 1];
+    const uint64_t mask = (uint64_t(1) << width) - 1;   // adc_mul, marin.cl:194-201
+    if (a == 1) {
+      const uint64_t r = u + carry;
+      dg[k] = __builtin_amdgcn_ubfe(uint32_t(r), 0u, width);
+      carry = r >> width;
+    } else {
+      const uint64_t dlo = u & mask, chi = u >> width;
+      const uint64_t r = dlo * a + carry;
+      dg[k] = uint32_t(r & mask);
+      carry = (r >> width) + chi * a;
+    }
+  }
+  // ---- hand the run carries to the next tile in digit order, take those of the previous one ----
+  if (!pln) __hip_atomic_store(&xbuf[size_t(T) * 256 + t], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are at the memory side before the flag can be seen
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&flags[T], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t Tdep = T ? T - 1 : NT - 1;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t ok = 1, spins = 0;
+    while (int32_t(__hip_atomic_load(&flags[Tdep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+      if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kChainTimeoutTicks) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wait_ok = ok;
+  }
+  __syncthreads();
+  {
+    // previous run in digit order (v2::carry_in_of): same row of the previous tile; the first tile wraps to the last tile of the previous row
+    const size_t src = T ? size_t(T - 1) * 256 + t : size_t(NT - 1) * 256 + (t ? t - 1 : 255u);
+    const uint64_t cin = __hip_atomic_load(&xbuf[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v2::apply_carry_in<8>(pl, di, 0, wait_ok ? cin : 0, dg);
+  }
+  // ---- front sweep of the same tile for the next squaring (k1_cols256_planes) ----
+  const uint32_t nowrap = ~di;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t d = dg[2 * c] ^ ((dg[2 * c] ^ dg[2 * c + 1]) & (0u - pln));
+    const uint32_t sh = nowrap >> (4 * c + 1 + 2 * pln);
+    x[c] = gf::mul_u32(tah, d << (sh & 1u));
+  }
+  if (sub != 0 && T == 0 && threadIdx.x == 0) x[0] = gf::sub(x[0], uint64_t(sub));
+#define WI(k) m2(idx_e(t, k))
+#define RI(j) m2(idx_a(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w1);
+#define WI(k) idx_a(t, k)
+#define RI(j) idx_b(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w2);
+#define WI(k) idx_b(t, k)
+#define RI(j) idx_c(t, j)
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x); twiddle3w(x, w3);
+#define WI(k) m2(idx_c(t, k))
+#define RI(j) m2(idx_d(t, j))
+  V3_EXCHW(X, x, pln, WI, RI)
+#undef WI
+#undef RI
+  dft4w<false>(x);
+  {
+    uint64_t ca = fca0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Wbuf[2 * (size_t(row0 + rev2(j)) * pl.M2 + i2) + pln] = gf::mul(x[j], ca);
+      if (j < 3) ca = gf::mul(ca, fB);
+    }
+  }
+}
+
+#endif   // MI355_EXPERIMENTAL
+
 // chain starts and ratios of the four-step twiddle chains (same thread map as the last stage of k1_cols256 / first stage of k3_cols256):
 // F0f[T][t] = omega_m^(i2 kb) TB[2 i2], F0i the inverse with TBi, FBf[i2] = omega_m^(64 i2), FBi its inverse
 __global__ void __launch_bounds__(kThreads) k_build_f0(DevPlan pl, uint64_t* __restrict__ f0f, uint64_t* __restrict__ f0i, uint64_t* __restrict__ fbf,
@@ -721,6 +893,25 @@ hipError_t v3_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
 }
 // columns: one plane per thread where the tiles make a single round (at most two per CU; MI355_TUNE bit 10 forces the pair form, bit 11 the plane form)
 static bool cols_planes(const DevPlan& pl) { return ((pl.M2 / 4 <= 512) && !(pl.tune & 1024)) || (pl.tune & 2048); }
+#if defined(MI355_EXPERIMENTAL)
+// back of one squaring + front of the next in one launch: only where every tile of the launch is resident at once (the groups wait for
+// each other's carry words) and the plane form is the one in use; 0: not served.  MI355_TUNE bit 12 switches it off (A/B runs).
+uint32_t v3_chain_tiles(const DevPlan& pl, int device) {
+  if (!v3_cols_shape(pl) || !cols_planes(pl) || (pl.tune & 4096)) return 0;
+  int per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v3::k31_cols256_planes, int(2 * v3::kThreads), v3::kLdsBytes + 16) != hipSuccess || per_cu < 1) return 0;
+  const uint32_t tiles = pl.M2 / 4, room = uint32_t(per_cu) * uint32_t(prop.multiProcessorCount);
+  return tiles <= room ? tiles : 0;
+}
+// xbuf: tiles x 256 carry words; flags: tiles words (+ the error word at flags[tiles]); epoch: > every epoch used before on these flags
+hipError_t v3_launch_backfront(const DevPlan& pl, uint64_t* W, uint32_t a, uint32_t sub, uint64_t* xbuf, uint32_t* flags, uint32_t epoch, hipStream_t s) {
+  const uint32_t tiles = pl.M2 / 4;
+  hipLaunchKernelGGL(v3::k31_cols256_planes, dim3(tiles), dim3(2 * v3::kThreads), v3::kLdsBytes, s, pl, W, a, sub, xbuf, flags, flags + tiles, epoch);
+  return hipGetLastError();
+}
+#endif
 hipError_t v3_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s) {
   if (cols_planes(pl)) hipLaunchKernelGGL(v3::k1_cols256_planes, dim3(pl.M2 / 4), dim3(2 * v3::kThreads), v3::kLdsBytes, s, pl, digits, cbuf_in, sub, W);
   else hipLaunchKernelGGL(v3::k1_cols256, dim3(pl.M2 / 4), dim3(v3::kThreads), v3::kLdsBytes, s, pl, digits, cbuf_in, sub, W);

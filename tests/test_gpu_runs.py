@@ -24,7 +24,9 @@ def Engine(*a, **k):
 # exponent, plan: two-level generic plans with runs of at least four digits (C >= 2), power-of-two and radix-5 columns, one tile .. 512 rows
 RUN_CASES = [(127, "m2=2,c=2"), (521, "m2=4,c=2"), (1801, "m2=8,c=4"), (3997, "m2=16,c=4"), (9941, "m2=64,c=8"), (9941, "m2=4,c=4"),
              (13967, None), (44497, None), (102701, None), (400063, "m2=64,c=4"), (1001, "m2=2,c=2"), (2976221, None), (9815459, None),
-             (19000013, None)]
+             (19000013, None),
+             # columns of 256 x 4 on the radix-4 set, 2 .. 16 tiles (the experimental library runs these as back + front in one launch)
+             (86243, "m2=8,c=4"), (132049, "m2=16,c=4"), (756839, "m2=64,c=4")]
 
 
 @pytest.mark.parametrize("p,plan", RUN_CASES)

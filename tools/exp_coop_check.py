@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Checks of the one-cooperative-launch squaring kernel (kernels.hip k_coop), which is NOT in the product library: it was measured
-slower than three launches per squaring and is only built into libmi355_engine_exp.so (`make -C prmers_amd/csrc exp`).
+"""Checks of the experiments that are NOT in the product library and only built into libmi355_engine_exp.so (`make -C prmers_amd/csrc exp`):
+the one-cooperative-launch squaring kernel (kernels.hip k_coop: measured slower than three launches per squaring, DESIGN history 5.2c) and the
+back + front sweep in one launch for runs of squarings on the small shapes (kernels_v3.hip k31_cols256_planes: -2 % at C2 for inter-group
+waits, profiles/r04_ab_chain_backfront.txt).
 
     MI355_ENGINE_LIB=prmers_amd/libmi355_engine_exp.so MI355_COOP=1 python tools/exp_coop_check.py          # on an MI355X box
 
@@ -41,6 +43,20 @@ def main():
             for _ in range(9): o.square_mul(0); o.sub(0, 2)
             assert np.array_equal(e.digits(0), o.digits(0)), (p, plan)
         print("ok", p, plan)
+    # the other experiment of the library: back + front in one launch for runs of squarings on the radix-4 column shapes
+    # (kernels_v3.hip k31_cols256_planes, profiles/r04_ab_chain_backfront.txt): square_mul_n against the oracle
+    for p, plan in [(86243, "m2=8,c=4"), (132049, "m2=16,c=4"), (756839, "m2=64,c=4"), (9815459, None)]:
+        rng = np.random.default_rng(p)
+        x0 = int.from_bytes(rng.bytes((p + 7) // 8), "little") % ((1 << p) - 1)
+        o = orc.Oracle(p, 2); o.set_value(0, x0)
+        with Engine(p, 2, plan=plan) as e:
+            e.set_int(0, x0)
+            e.square_mul_n(0, 17); [o.square_mul(0) for _ in range(17)]
+            assert np.array_equal(e.digits(0), o.digits(0)), (p, plan)
+            e.square_mul_n(0, 9, 3, 2)
+            for _ in range(9): o.square_mul(0, 3); o.sub(0, 2)
+            assert np.array_equal(e.digits(0), o.digits(0)), (p, plan)
+        print("ok chained", p, plan)
     os.environ["MI355_COOP_FAULT"] = "1"
     with Engine(9941, 2, plan="m2=16,c=4") as e:
         e.set(0, 3); e.square_mul(0)
