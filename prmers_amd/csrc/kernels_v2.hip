@@ -237,6 +237,186 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows of 2048, one row to a tile, ONE PLANE PER THREAD (round 4).  The two planes of a pair go through the same GF(P)-linear transform and
+// meet only in the pointwise step, so the "two rows to a tile" kernel above runs unchanged on 64-bit words with the row bit read as the plane
+// bit: a tile is one row of 2048 pairs = 4096 words, 512 threads x 8 words, the first-stage registers 4 pl .. 4 pl + 3 are plane pl of the
+// four pairs a thread loads (16-byte loads and stores as before), after the last forward exchange plane = lane >> 5, and the pointwise step
+// trades words with lane ^ 32 (ds_bpermute: crossbar only, no LDS memory).  Half the registers and half the serial work per thread of the
+// pair form, twice the tiles: where two rows to a tile leave CUs without a tile (n = 2^20: 128 tiles) or with one group of eight waves
+// (n = 2^21) this fills the chip.  LDS: 32 KiB of 8-byte slots, map i ^ ((i >> 3) & 31) (conflict-free for the 16-lane / 32-lane groups
+// 64-bit accesses are served in: thread-major, strided and wave-major orders alike).
+// Multiplicand image (mode 2 -> mode 1): word 512 k4 + t of the row, i.e. plane-major inside 64-word runs -- private to this kernel.
+__device__ __forceinline__ uint32_t phys8(uint32_t i) { return i ^ ((i >> 3) & 31u); }
+__device__ __forceinline__ uint64_t swap32(uint64_t v, uint32_t partner_byte) {   // the word lane ^ 32 holds
+  const uint32_t lo = uint32_t(__builtin_amdgcn_ds_bpermute(int(partner_byte), int(uint32_t(v))));
+  const uint32_t hi = uint32_t(__builtin_amdgcn_ds_bpermute(int(partner_byte), int(uint32_t(v >> 32))));
+  return (uint64_t(hi) << 32) | lo;
+}
+template <int W, bool INV>
+__device__ __forceinline__ void seam64w_const(uint64_t (&x)[8]) {
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const unsigned f = (gf::LOG2_W64 * unsigned(k) * unsigned(W)) % 192u;
+    x[k] = gf::mul_pow2(x[k], INV ? (192u - f) % 192u : f);
+  }
+}
+template <bool INV, bool FOLD0 = false>
+__device__ __forceinline__ void seam64w(uint64_t (&x)[8], uint32_t wave) {
+  switch (wave) {
+    case 0:
+      if (FOLD0) { x[1] = gf::fold(x[1]); x[2] = gf::fold(x[2]); x[3] = gf::fold(x[3]); x[5] = gf::fold(x[5]); }
+      break;
+    case 1: seam64w_const<1, INV>(x); break;
+    case 2: seam64w_const<2, INV>(x); break;
+    case 3: seam64w_const<3, INV>(x); break;
+    case 4: seam64w_const<4, INV>(x); break;
+    case 5: seam64w_const<5, INV>(x); break;
+    case 6: seam64w_const<6, INV>(x); break;
+    default: seam64w_const<7, INV>(x); break;
+  }
+}
+template <int W, bool INV>
+__device__ __forceinline__ void seam32w_const(uint64_t (&x)[8]) {   // x[4 pl + k1'] *= omega_32^(+-k1' W)
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    if ((k & 3) == 0) continue;
+    const unsigned f = (2u * gf::LOG2_W64 * unsigned(k & 3) * unsigned(W)) % 192u;
+    x[k] = gf::mul_pow2(x[k], INV ? (192u - f) % 192u : f);
+  }
+}
+template <bool INV>
+__device__ __forceinline__ void seam32w(uint64_t (&x)[8], uint32_t wave) {
+  switch (wave) {
+    case 0: break;
+    case 1: seam32w_const<1, INV>(x); break;
+    case 2: seam32w_const<2, INV>(x); break;
+    case 3: seam32w_const<3, INV>(x); break;
+    case 4: seam32w_const<4, INV>(x); break;
+    case 5: seam32w_const<5, INV>(x); break;
+    case 6: seam32w_const<6, INV>(x); break;
+    default: seam32w_const<7, INV>(x); break;
+  }
+}
+#define EXCHW_THREAD_MAJOR_TO_STRIDED(X, x, t)                      \
+  lds_barrier();                                                    \
+  _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) X[phys8((t) * 8 + r_)] = x[r_]; \
+  lds_barrier();                                                    \
+  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) x[j_] = X[phys8(j_ * 512 + (t))];
+#define EXCHW_STRIDED_TO_THREAD_MAJOR(X, x, t)                      \
+  lds_barrier();                                                    \
+  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) X[phys8(j_ * 512 + (t))] = x[j_]; \
+  lds_barrier();                                                    \
+  _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) x[r_] = X[phys8((t) * 8 + r_)];
+
+constexpr uint32_t kLdsBytesPlanes = 4096 * 8;
+
+template <int mode>
+__global__ void __launch_bounds__(512, 4) k2_rows2048_planes(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
+                                                             uint64_t* __restrict__ Wout, uint32_t sub) {
+  uint64_t* X = reinterpret_cast<uint64_t*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t row = blockIdx.x;
+  const P2* in = reinterpret_cast<const P2*>(Win) + size_t(row) * 2048;
+  P2* out = reinterpret_cast<P2*>(Wout) + size_t(row) * 2048;
+  uint64_t x[8];
+  // pointwise stage: thread (k3|pl|k1'|k2) holds plane pl = lane >> 5 of X[kb + 256 k4], kb = k1' + 4 k2 + 32 k3
+  const uint32_t pln = lane >> 5, partner = ((lane ^ 32u) << 2);
+  const uint32_t kb = ((lane >> 3) & 3u) + 4 * (lane & 7) + 32 * wave;
+  const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;       // column-DFT slot -> frequency (kernels.hip freq1)
+  const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * kb;
+  const uint64_t rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)], rho_hi = pl.TWhi[erho >> pl.twh];
+
+  // ---- forward ----
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { const P2 v = in[512 * d + t]; x[d] = v.a; x[4 + d] = v.b; }
+  if (sub != 0 && t == 0) x[0] = gf::sub(x[0], uint64_t(sub));   // LL's -2: element 0, plane a
+  dft4<false>(x[0], x[1], x[2], x[3]); dft4<false>(x[4], x[5], x[6], x[7]);
+  seam32w<false>(x, wave);
+  uint64_t sw[8];
+  {
+    const uint32_t k1 = t & 7, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S2r + b * 64 + k1 * 8;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[k2];
+  }
+  EXCHW_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  gf::dft8<false, 2>(x);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) x[k2] = gf::mul(x[k2], sw[k2]);
+  EXCHW_THREAD_MAJOR_TO_STRIDED(X, x, t)
+  gf::dft8<false, 1>(x);
+  seam64w<false, true>(x, wave);
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) X[phys8(wave * 512 + k * 64 + lane)] = x[k];
+  lds_barrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = X[phys8(j * 512 + t)];
+  gf::dft8<false, 2>(x);
+
+  if (mode == 2) {
+    uint64_t* img = Wout + size_t(row) * 4096;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) img[512 * j + t] = x[j];   // (un-folded sums: a multiplication reads them)
+    return;
+  }
+
+  // ---- pointwise: (a + b t)^2 or (a + b t)(ya + yb t) mod (t^2 - rho), rho = rho0 omega_8^k4; plane a computes and keeps the t^0 word ----
+  {
+    const uint64_t rho0 = gf::mul(rho_lo, rho_hi);
+    const uint64_t* Y = Yimg + size_t(row) * 4096;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      const unsigned sh = 24u * (k4 & 3);
+      const bool neg = (k4 == 1) || (k4 == 3) || (k4 == 4) || (k4 == 6);
+      const uint64_t w = x[k4];
+      uint64_t keep, send;
+      if (mode == 0) {
+        const uint64_t o = swap32(w, partner);
+        keep = gf::sqr(w);                                            // a^2 | b^2
+        send = gf::mul(pln ? keep : w, pln ? rho0 : o);               // a b | b^2 rho0
+        if (pln) send = gf::mul_pow2(send, sh);
+      } else {
+        const uint64_t y = Y[512 * k4 + t], yo = Y[512 * k4 + (t ^ 32u)];
+        keep = gf::mul(w, y);                                         // a ya | b yb
+        send = gf::mul(w, yo);                                        // a yb | b ya
+        if (pln) { const uint64_t q = gf::mul_pow2(gf::mul(keep, rho0), sh); keep = send; send = q; }   // plane b keeps b ya, sends b yb rho
+      }
+      const uint64_t recv = swap32(send, partner);
+      if (mode == 0) x[k4] = pln ? gf::dbl(recv) : (neg ? gf::sub(keep, recv) : gf::add(keep, recv));
+      else x[k4] = pln ? gf::add(keep, recv) : (neg ? gf::sub(keep, recv) : gf::add(keep, recv));
+    }
+  }
+
+  // ---- inverse (mirror) ----
+  gf::dft8<true>(x);
+  lds_barrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) X[phys8(j * 512 + t)] = x[j];
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = X[phys8(wave * 512 + k * 64 + lane)];
+  seam64w<true>(x, wave);
+  gf::dft8<true, 2>(x);
+  {
+    const uint32_t k1 = t & 7, b = t >> 3;
+    const uint64_t* __restrict__ tw = pl.S2ri + b * 64 + k1 * 8;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) sw[k2] = tw[k2];
+  }
+  EXCHW_STRIDED_TO_THREAD_MAJOR(X, x, t)
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) x[k2] = gf::mul(x[k2], sw[k2]);
+  gf::dft8<true>(x);
+  EXCHW_STRIDED_TO_THREAD_MAJOR(X, x, t)
+  seam32w<true>(x, wave);
+  dft4<true>(x[0], x[1], x[2], x[3]); dft4<true>(x[4], x[5], x[6], x[7]);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) out[512 * d + t] = P2{x[d], x[4 + d]};
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column tiles, M1 = 512 R = R.8.8.8 with R in {1, 2, 4} and C = 8 / R pairs per run (tile = 4096 pairs).
 // Tile element (i1, c), i1 = 512 d1 + 64 d2 + 8 d3 + d4 (d1 < R).  kc = k1 C + c is a 3-bit register /
 // thread field throughout.
@@ -615,10 +795,14 @@ hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 
 // rows of 2048 go two to a tile: only where that still gives at least one work-group per CU (n = 2^21, 5 2^20); below that the generic
 // rows win.  MI355_TUNE bit 6 switches them off (A/B runs)
+// Below 512 rows (n = 2^20) a row is a tile of its own with one plane per thread (k2_rows2048_planes).  MI355_TUNE bit 13 switches that off,
+// bit 14 forces it for every row count (A/B runs)
+static bool rows2048_planes(const DevPlan& pl) { return pl.M2 == 2048 && ((pl.M1 < 512 && !(pl.tune & 8192)) || (pl.tune & 16384)); }
 bool v2_rows_supported(const DevPlan& pl) {
   if (v3_rows_shape(pl)) return true;   // rows of 1024: the radix-4 set (kernels_v3.hip)
   if (pl.S2r == nullptr) return false;
   if (pl.M2 == 4096 || pl.M2 == 8192) return true;
+  if (rows2048_planes(pl)) return true;
   return pl.M2 == 2048 && pl.M1 % 2 == 0 && pl.M1 >= 512 && !(pl.tune & 64);
 }
 // columns: M1 = 512 R, R in {1, 2, 4}, with C = 8 / R pairs per run (one 4096-pair tile per work-group)
@@ -646,7 +830,11 @@ hipError_t v2_configure() {
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
   if (v3_rows_shape(pl)) return v3_launch_middle(pl, Win, Y, Wout, mode, sub, s);
 #define MI355_ROWS(MODE, HH) hipLaunchKernelGGL((v2::k2_rows4096<MODE, HH>), dim3(pl.M1), dim3(512 * HH), HH * v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
-  if (pl.M2 == 2048) {   // two rows to a tile
+  if (rows2048_planes(pl)) {
+#define MI355_ROWS_PL(MODE) hipLaunchKernelGGL((v2::k2_rows2048_planes<MODE>), dim3(pl.M1), dim3(512), v2::kLdsBytesPlanes, s, pl, Win, Y, Wout, sub)
+    switch (mode) { case 0: MI355_ROWS_PL(0); break; case 1: MI355_ROWS_PL(1); break; default: MI355_ROWS_PL(2); break; }
+#undef MI355_ROWS_PL
+  } else if (pl.M2 == 2048) {   // two rows to a tile
 #define MI355_ROWS_TWO(MODE) hipLaunchKernelGGL((v2::k2_rows4096<MODE, 1, 1>), dim3(pl.M1 / 2), dim3(512), v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
     switch (mode) { case 0: MI355_ROWS_TWO(0); break; case 1: MI355_ROWS_TWO(1); break; default: MI355_ROWS_TWO(2); break; }
 #undef MI355_ROWS_TWO

