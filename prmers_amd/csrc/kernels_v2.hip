@@ -795,9 +795,13 @@ hipError_t v2_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, ui
 
 // rows of 2048 go two to a tile: only where that still gives at least one work-group per CU (n = 2^21, 5 2^20); below that the generic
 // rows win.  MI355_TUNE bit 6 switches them off (A/B runs)
-// Below 512 rows (n = 2^20) a row is a tile of its own with one plane per thread (k2_rows2048_planes).  MI355_TUNE bit 13 switches that off,
-// bit 14 forces it for every row count (A/B runs)
-static bool rows2048_planes(const DevPlan& pl) { return pl.M2 == 2048 && ((pl.M1 < 512 && !(pl.tune & 8192)) || (pl.tune & 16384)); }
+// Below 512 rows (n = 2^20) and at 1280 rows (n = 5 2^20: 640 two-row tiles are 1.25 rounds of the chip) a row is a tile of its own with
+// one plane per thread (k2_rows2048_planes): same-box A/B 0.0428 -> 0.0378 ms at n = 2^20, 0.1182 -> 0.1137 at 5 2^20, but 0.0571 -> 0.0586
+// at n = 2^21 (512 rows: two to a tile stay), profiles/r04_ab_rows2048_planes.txt.  MI355_TUNE bit 13 switches the plane form off, bit 14
+// forces it for every row count (A/B runs)
+static bool rows2048_planes(const DevPlan& pl) {
+  return pl.M2 == 2048 && (((pl.M1 < 512 || pl.M1 == 1280) && !(pl.tune & 8192)) || (pl.tune & 16384));
+}
 bool v2_rows_supported(const DevPlan& pl) {
   if (v3_rows_shape(pl)) return true;   // rows of 1024: the radix-4 set (kernels_v3.hip)
   if (pl.S2r == nullptr) return false;

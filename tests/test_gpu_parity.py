@@ -36,6 +36,8 @@ SMALL_CASES = [
     # their own rows of 1024: p = 9815459 below), rows of 1024 over generic columns of 8 .. 64
     (86243, "m2=8,c=4"), (132049, "m2=16,c=4"), (300007, "m2=32,c=4"), (756839, "m2=64,c=4"),
     (300007, "m2=1024"), (600011, "m2=1024"), (1200007, "m2=1024,c=4"), (2976221, "m2=1024"),
+    # rows of 2048 with one plane per thread (kernels_v2.hip k2_rows2048_planes: fewer than 512 rows) over generic and radix-4 columns
+    (300007, "m2=2048"), (600011, "m2=2048"), (1200007, "m2=2048,c=4"), (2976221, "m2=2048"), (4800007, "m2=2048,c=4"),
     # columns of 1280 = 5 x 256 on the register-resident radix-5 kernels (640 threads per tile), generic and radix-8 rows
     (400063, "m2=8,c=4"), (800283, "m2=16,c=4"), (1600589, "m2=32,c=4"),
     # rows of 8192 (two 4096-point halves under one radix-2 level, 1024 threads)
@@ -247,10 +249,11 @@ def test_c2_9815459_first_iterations():
                 assert np.array_equal(e.digits(0), o.digits(0)), it
 
 
-@pytest.mark.parametrize("p,n", [(9815459, 1 << 19), (4800007, 1 << 18), (50000017, 5 << 19)])
+@pytest.mark.parametrize("p,n", [(9815459, 1 << 19), (4800007, 1 << 18), (50000017, 5 << 19), (19000013, 1 << 20)])
 def test_radix4_set_full_size_operations(p, n):
     """The shapes of the register-resident radix-4 kernels at full-size digits (kernels_v3.hip): C2 (columns of 256 x 4 + rows of 1024),
-    n = 2^18 (rows of 1024 over generic columns of 128) and n = 5 2^19 (rows of 1024 under the radix-5 columns): squarings with a factor,
+    n = 2^18 (rows of 1024 over generic columns of 128), n = 5 2^19 (rows of 1024 under the radix-5 columns) and n = 2^20 (columns of
+    256 x 4 around the plane-per-thread rows of 2048, kernels_v2.hip k2_rows2048_planes): squarings with a factor,
     the LL step with the subtraction deferred into the next sweep, set_multiplicand / mul (forward-only and multiply modes of the row
     kernel), the fused back sweeps (mul_add, square_mul_copy) -- digit vectors against the oracle."""
     o = orc.Oracle(p, 4)
@@ -335,6 +338,33 @@ def test_rows_of_2048_two_to_a_tile(p, plan, shape, monkeypatch):
             e.square_mul(0); o.square_mul(0)
             assert np.array_equal(e.digits(0), o.digits(0))
             assert e.res64(0) == o.res64(0)
+
+
+@pytest.mark.parametrize("p", [30402457, 100000007])
+def test_rows_of_2048_one_plane_per_thread_forced(p, monkeypatch):
+    """k2_rows2048_planes forced (MI355_TUNE bit 14) where the default keeps two rows to a tile (n = 2^21, 5 2^20): more than one round of
+    tiles per CU, radix-8 and radix-5 columns around it -- squarings, x a, LL step, multiplicand / mul against the oracle's digits."""
+    o = orc.Oracle(p, 3)
+    rng = np.random.default_rng(p + 1)
+    w = o.widths().astype(np.uint64)
+    d0 = (rng.integers(0, 1 << 62, o.n, dtype=np.uint64) & ((np.uint64(1) << w) - np.uint64(1))) | (w << np.uint64(32))
+    monkeypatch.setenv("MI355_TUNE", "16384")
+    with Engine(p, 4) as e:
+        e.set_digits(0, d0); o.set_digits(0, d0)
+        for it in range(3):
+            e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.square_mul(0, 3); o.square_mul(0, 3)
+        e.sub(0, 2); o.sub(0, 2)
+        e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        e.copy(1, 0); o.copy(1, 0)
+        e.square_mul(1); o.square_mul(1)
+        e.set_multiplicand(2, 1); o.set_multiplicand(2, 1)
+        e.mul(0, 2, 3); o.mul(0, 2, 3)
+        e.square_mul(0); o.square_mul(0)
+        assert np.array_equal(e.digits(0), o.digits(0))
+        assert e.res64(0) == o.res64(0)
 
 
 def test_full_size_properties_no_oracle():
