@@ -81,9 +81,7 @@ __device__ __forceinline__ void dft_rows_first(P2 (&x)[8]) {   // the first-stag
   dft4<INV>(x[4].a, x[5].a, x[6].a, x[7].a); dft4<INV>(x[4].b, x[5].b, x[6].b, x[7].b);
 }
 
-#undef MI355_TILE_BARRIER
-#define MI355_TILE_BARRIER() do { if constexpr (SOFT) half_barrier(hb_cnt, hb_target, lane); else lds_barrier(); } while (0)
-template <int mode, int H, int RL = 0, bool SOFT = false>
+template <int mode, int H, int RL = 0>
 __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint64_t* __restrict__ Win, const uint64_t* __restrict__ Yimg,
                                                           uint64_t* __restrict__ Wout, uint32_t sub) {
   static_assert(RL == 0 || (RL == 1 && H == 1), "two rows to a tile only with one tile per work-group");
@@ -94,11 +92,6 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   if (H == 1) boost_if_late(pl.boost_rows);
   P2* X = reinterpret_cast<P2*>(smem_v2) + h * kLdsSlots;
   const uint32_t t = threadIdx.x & 511, lane = t & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7);
-  // SOFT (H = 2): the two halves keep their own exchange barriers (half_barrier); MI355_TUNE bit 15 launches the s_barrier form
-  static_assert(!SOFT || H == 2, "half barriers: two 4096-point halves per work-group");
-  uint32_t* hb_cnt = reinterpret_cast<uint32_t*>(smem_v2 + 2 * kLdsBytes) + 16 * h;
-  uint32_t hb_target = 0;
-  if (SOFT) { if (t == 0) *hb_cnt = 0; __syncthreads(); }
   const uint32_t tile = PROBE_BLOCK(pl);
   const uint32_t row = HALF ? (tile << RL) + (lane >> (6 - RL)) : tile;    // several rows: the row this thread's S4 outputs (and pointwise words) belong to
   PROBE_BEGIN(pl)
@@ -152,10 +145,10 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)
   dft8p<false, 1>(x);
   seam64<false, true>(x, wave);
-  MI355_TILE_BARRIER();
+  lds_barrier();
 #pragma unroll
   for (int k = 0; k < 8; ++k) X[phys(wave * 512 + k * 64 + lane)] = x[k];
-  MI355_TILE_BARRIER();
+  lds_barrier();
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = X[phys(j * 512 + t)];
   dft8p<false, 2>(x);   // mode 2 stores them for a later multiplication, the pointwise stage multiplies
@@ -196,10 +189,10 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
 
   // ---- inverse (mirror) ----
   dft8p<true>(x);
-  MI355_TILE_BARRIER();
+  lds_barrier();
 #pragma unroll
   for (int j = 0; j < 8; ++j) X[phys(j * 512 + t)] = x[j];
-  MI355_TILE_BARRIER();
+  lds_barrier();
 #pragma unroll
   for (int k = 0; k < 8; ++k) x[k] = X[phys(wave * 512 + k * 64 + lane)];
   seam64<true>(x, wave);
@@ -242,9 +235,6 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
   PROBE_END(pl)
 }
-
-#undef MI355_TILE_BARRIER
-#define MI355_TILE_BARRIER() lds_barrier()
 
 // ---------------------------------------------------------------------------------------------
 // Rows of 2048, one row to a tile, ONE PLANE PER THREAD (round 4).  The two planes of a pair go through the same GF(P)-linear transform and
@@ -832,8 +822,7 @@ bool v2_cols_supported(const DevPlan& pl) {
     if (e_ != hipSuccess) return e_; }
 hipError_t v2_configure() {
   MI355_SET_LDS((v2::k2_rows4096<0, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 1>), v2::kLdsBytes)
-  MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes + 128) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes + 128) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes + 128)
-  MI355_SET_LDS((v2::k2_rows4096<0, 2, 0, true>), 2 * v2::kLdsBytes + 128) MI355_SET_LDS((v2::k2_rows4096<1, 2, 0, true>), 2 * v2::kLdsBytes + 128) MI355_SET_LDS((v2::k2_rows4096<2, 2, 0, true>), 2 * v2::kLdsBytes + 128)
+  MI355_SET_LDS((v2::k2_rows4096<0, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 2>), 2 * v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 2>), 2 * v2::kLdsBytes)
   MI355_SET_LDS((v2::k2_rows4096<0, 1, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<1, 1, 1>), v2::kLdsBytes) MI355_SET_LDS((v2::k2_rows4096<2, 1, 1>), v2::kLdsBytes)
   MI355_SET_LDS(v2::k1_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k1_cols<4>, v2::kLdsBytes)
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
@@ -844,7 +833,7 @@ hipError_t v2_configure() {
 #undef MI355_SET_LDS
 hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64_t* Y, uint64_t* Wout, int mode, uint32_t sub, hipStream_t s) {
   if (v3_rows_shape(pl)) return v3_launch_middle(pl, Win, Y, Wout, mode, sub, s);
-#define MI355_ROWS(MODE, HH) hipLaunchKernelGGL((v2::k2_rows4096<MODE, HH>), dim3(pl.M1), dim3(512 * HH), HH * v2::kLdsBytes + (HH == 2 ? 128 : 0), s, pl, Win, Y, Wout, sub)
+#define MI355_ROWS(MODE, HH) hipLaunchKernelGGL((v2::k2_rows4096<MODE, HH>), dim3(pl.M1), dim3(512 * HH), HH * v2::kLdsBytes, s, pl, Win, Y, Wout, sub)
   if (rows2048_planes(pl)) {
 #define MI355_ROWS_PL(MODE) hipLaunchKernelGGL((v2::k2_rows2048_planes<MODE>), dim3(pl.M1), dim3(512), v2::kLdsBytesPlanes, s, pl, Win, Y, Wout, sub)
     switch (mode) { case 0: MI355_ROWS_PL(0); break; case 1: MI355_ROWS_PL(1); break; default: MI355_ROWS_PL(2); break; }
@@ -855,12 +844,8 @@ hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
 #undef MI355_ROWS_TWO
   } else if (pl.M2 == 4096) {   // one instantiation per mode: the squaring kernel carries no multiply / image code
     switch (mode) { case 0: MI355_ROWS(0, 1); break; case 1: MI355_ROWS(1, 1); break; default: MI355_ROWS(2, 1); break; }
-  } else if (pl.tune & 32768u) {
+  } else {
     switch (mode) { case 0: MI355_ROWS(0, 2); break; case 1: MI355_ROWS(1, 2); break; default: MI355_ROWS(2, 2); break; }
-  } else {   // rows of 8192: the two halves of a work-group on barriers of their own
-#define MI355_ROWS_SOFT(MODE) hipLaunchKernelGGL((v2::k2_rows4096<MODE, 2, 0, true>), dim3(pl.M1), dim3(1024), 2 * v2::kLdsBytes + 128, s, pl, Win, Y, Wout, sub)
-    switch (mode) { case 0: MI355_ROWS_SOFT(0); break; case 1: MI355_ROWS_SOFT(1); break; default: MI355_ROWS_SOFT(2); break; }
-#undef MI355_ROWS_SOFT
   }
 #undef MI355_ROWS
   return hipGetLastError();

@@ -145,56 +145,18 @@ __device__ __forceinline__ void lds_barrier() {
 #define PROBE_GRID(pl) gridDim.x
 #endif
 
-// exchange helpers: barrier, write 8, barrier, read 8 (MI355_TILE_BARRIER: the barrier of the tile's threads; the row kernel of 8192
-// redefines it around its body, kernels_v2.hip)
-#define MI355_TILE_BARRIER() lds_barrier()
+// exchange helpers: barrier, write 8, barrier, read 8
 #define EXCH_THREAD_MAJOR_TO_STRIDED(X, x, t)                      \
-  MI355_TILE_BARRIER();                                            \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) X[phys((t) * 8 + r_)] = x[r_]; \
-  MI355_TILE_BARRIER();                                            \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) x[j_] = X[phys(j_ * 512 + (t))];
 
 #define EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)                      \
-  MI355_TILE_BARRIER();                                            \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) X[phys(j_ * 512 + (t))] = x[j_]; \
-  MI355_TILE_BARRIER();                                            \
+  lds_barrier();                                                   \
   _Pragma("unroll") for (int r_ = 0; r_ < 8; ++r_) x[r_] = X[phys((t) * 8 + r_)];
-
-// Barrier of ONE 512-thread half of a 1024-thread work-group (rows of 8192: each half runs a 4096-point transform in its own LDS half).
-// s_barrier would keep the two halves in lock step -- all sixteen waves of the CU wait at the same exchanges and the VALU idles a third of
-// the time (a group alone on a CU: DESIGN.md section 5) -- so the halves count arrivals in an LDS word of their own instead and drift apart
-// like two work-groups do: one ds_add per wave, then polls of the word.  Every wave of the half reaches every barrier, the poll is bounded.
-__device__ __forceinline__ void half_barrier(uint32_t* cnt, uint32_t& target, uint32_t /*lane*/) {
-  // One asm statement (the compiler sees straight-line code: as a C++ loop the fourteen polls of the row kernel split its body into regions
-  // and the kernel spilled 34 registers).  Lane 0 of the wave adds 1 (all 64 lanes are active in these kernels), then the wave polls.
-  target += 8;   // waves per half
-  const uint32_t addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)cnt);   // LDS byte address
-  uint32_t tmp;
-  uint64_t sv;
-  uint32_t seen, spins;
-  asm volatile(
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "s_mov_b64 %[sv], exec\n\t"
-      "s_mov_b64 exec, 1\n\t"
-      "ds_add_u32 %[addr], %[one]\n\t"
-      "s_mov_b64 exec, %[sv]\n\t"
-      "s_mov_b32 %[spins], 0\n"
-      "1%=:\n\t"
-      "ds_read_b32 %[tmp], %[addr]\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_readfirstlane_b32 %[seen], %[tmp]\n\t"
-      "s_cmp_ge_u32 %[seen], %[target]\n\t"
-      "s_cbranch_scc1 2%=f\n\t"
-      "s_add_u32 %[spins], %[spins], 1\n\t"
-      "s_cmp_lt_u32 %[spins], 0x400000\n\t"
-      "s_cbranch_scc0 2%=f\n\t"
-      "s_sleep 1\n\t"
-      "s_branch 1%=b\n"
-      "2%=:"
-      : [tmp] "=&v"(tmp), [sv] "=&s"(sv), [seen] "=&s"(seen), [spins] "=&s"(spins)
-      : [addr] "v"(addr), [one] "v"(1u), [target] "s"(target)
-      : "memory", "scc");
-}
 
 // previous run (in digit order) of run (T, i1); see kernels.hip
 __device__ __forceinline__ uint64_t carry_in_of(const DevPlan& pl, const uint64_t* cbuf, uint32_t T, uint32_t i1) {
