@@ -11,8 +11,9 @@
 //   * only the seam between two blocks is a general GF(P) multiplication (one per element and
 //     direction, from a universal omega_M table), against three per radix-4 level pair in the
 //     reference's schedule (marin.cl:304-318: fwd4/bck4 with r1, r23.s0, r23.s1).
-// Shapes served: rows M2 = 4096 (8.8.8.8) and 8192 (2 x 4096 under one radix-2 level); columns
-// M1 = 512 R (R.8.8.8, R = 1, 2, 4) with C = 8/R pairs per run.  Everything else runs on the generic set.
+// Shapes served: rows M2 = 4096 (8.8.8.8), 8192 (2 x 4096 under one radix-2 level) and 2048 (4.8.8.8: two rows to a tile, or one row with
+// one plane per thread -- k2_rows2048_planes below); columns M1 = 512 R (R.8.8.8, R = 1, 2, 4) with C = 8/R pairs per run.  The small
+// transforms run on the radix-4 set (kernels_v3.hip), columns of 1280 on kernels_v5.hip, everything else on the generic set.
 // Row order of the work buffer and digit layout are those of kernels.hip, so the two sets interoperate
 // kernel by kernel (the multiplicand image layout differs: an engine uses one middle kernel for both
 // set_multiplicand and mul).
@@ -22,7 +23,7 @@
 // multiplication or a canonical add/sub -- except the row kernel's last inverse stage, whose un-folded outputs the back sweep multiplies first --
 // so nothing non-canonical other than P reaches a canonical-only operand or a digit.
 //
-// LDS exchanges (P2 = 16 B slots, index skewed by i + i/8 against bank conflicts):
+// LDS exchanges (P2 = 16 B slots, slot map phys() of kernels_v2_common.hpp against bank conflicts):
 //   writer "thread-major": slot t*8 + r          reader: slot j*512 + t'
 //   writer "wave-major":   slot w*512 + r*64 + f(lane)   reader: slot j*512 + t'
 // which is the digit permutation that hands each thread the 8 elements of its next radix-8.
