@@ -235,6 +235,31 @@ def test_edge_values():
             e.square_mul(2)              # a multiplicand is not a residue
 
 
+@pytest.mark.parametrize("p", [9815459, 19000013, 50000017, 100000007, 136279841, 205271257])
+def test_extreme_digits_full_size(p):
+    """Every digit at its maximum (x = Mp - 1 = -1: the largest convolution sums and the longest carry chains the transform can see) at the
+    full-size shapes of every register-resident kernel set: (-1)^2 = 1, (-1)^2 * 3 = 3, then 3^2 - 2 through the deferred subtraction; digit
+    vectors against the oracle and the values by hand."""
+    o = orc.Oracle(p, 2)
+    w = o.widths().astype(np.uint64)
+    d = ((np.uint64(1) << w) - np.uint64(1)) | (w << np.uint64(32))
+    d[0] -= np.uint64(1)                                   # Mp - 1
+    with Engine(p, 2) as e:
+        e.set_digits(0, d); o.set_digits(0, d)
+        e.square_mul(0); o.square_mul(0)
+        got = e.digits(0)
+        assert np.array_equal(got, o.digits(0))
+        assert int(got[0] & np.uint64(0xFFFFFFFF)) == 1 and not np.any(got[1:] & np.uint64(0xFFFFFFFF))
+        e.set_digits(0, d); o.set_digits(0, d)
+        e.square_mul(0, 3); o.square_mul(0, 3)
+        e.sub(0, 2); o.sub(0, 2)
+        e.square_mul(0); o.square_mul(0)                   # (3 - 2)^2 = 1
+        got = e.digits(0)
+        assert np.array_equal(got, o.digits(0))
+        assert int(got[0] & np.uint64(0xFFFFFFFF)) == 1 and not np.any(got[1:] & np.uint64(0xFFFFFFFF))
+        assert e.res64(0) == 1
+
+
 def test_c2_9815459_first_iterations():
     """BASELINE config C2 (n = 2^19): first 60 squarings from 3, digits vs the oracle, then Gerbicz-style
     identity d * x^? skipped here (see test_prp_driver)."""
