@@ -137,8 +137,9 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
     b = ilog2(size_t(want_m2));
     if ((long(1) << b) != want_m2 || b > k || b < 1 || b > 13) throw std::runtime_error("bad m2 in plan spec");
   } else {
-    // very large transforms: 8192-pair rows (128 KiB) so that M1 stays <= 2048
-    while ((pl.m >> b) > 2048 && b < 13 && b < k) ++b;
+    // very large transforms: 8192-pair rows (128 KiB) so that M1 stays <= 2048 -- or 2560 = 5 x 512, which the register-resident radix-5
+    // columns serve with runs of two pairs (kernels_v5.hip, J = 1): n = 5 2^22 runs as 2560 x 4096 instead of 1280 x 8192
+    while ((pl.m >> b) > (pl.r5 == 5 ? 2560u : 2048u) && b < 13 && b < k) ++b;
     if (pl.r5 == 5 && (pl.m >> b) > 10240 && b < k) b = std::min(13, k);   // n = 5 2^26: rows of 8192, columns of 5 x 4096 (split sweeps)
   }
   pl.logM2 = uint32_t(b);
@@ -269,19 +270,21 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
         pl.DI[T * 256 + t] = w;
       }
   }
-  if (pl.r5 == 5 && pl.M1 == 1280 && pl.C == 4 && pl.M2 >= 8) {
-    // columns of 1280 = 5 x 256 (kernels_v2.hip, namespace v5): 640 threads per tile, thread t owns runs i1 = t and t + 640
+  if (pl.r5 == 5 && ((pl.M1 == 1280 && pl.C == 4) || (pl.M1 == 2560 && pl.C == 2)) && pl.M2 >= 8) {
+    // columns of 1280 = 5 x 256 and 2560 = 5 x 512 (kernels_v5.hip): 640 threads per tile, thread t owns the runs i1 = t + 640 d1
+    // (two runs of eight digits, or four of four)
+    const uint32_t NR = pl.M1 / 640, ND = 2 * pl.C;
     pl.DI.assign(pl.tiles() * 640, 0u);
     for (size_t T = 0; T < pl.tiles(); ++T)
       for (uint32_t t = 0; t < 640; ++t) {
         uint32_t w = 0;
-        for (uint32_t d1 = 0; d1 < 2; ++d1)
-          for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t i1 = 640 * d1 + t, i2 = uint32_t(T) * 4 + (k >> 1);
+        for (uint32_t d1 = 0; d1 < NR; ++d1)
+          for (uint32_t k = 0; k < ND; ++k) {
+            const uint32_t i1 = 640 * d1 + t, i2 = uint32_t(T) * pl.C + (k >> 1);
             const uint64_t sb = pl.SB[2 * i2 + (k & 1)], s = (uint64_t(pl.SA[i1]) + sb) % n;
             const uint64_t wa = (k & 1) ? pl.SA[pl.M1 + i1] : pl.SA[i1], wb = pl.SB[2 * i2];
             const uint32_t wbit = pl.width_of_s(s) - pl.q, wrap = (wa > 0 && wb > 0 && wa + wb <= n) ? 1u : 0u;
-            w |= (wbit | (wrap << 1)) << (2 * (d1 * 8 + k));
+            w |= (wbit | (wrap << 1)) << (2 * (d1 * ND + k));
           }
         pl.DI[T * 640 + t] = w;
       }

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 # exponent, plan: generic single-row, generic two-level (C = 1, 2, 4, 8), radix-5 columns, register-resident columns / rows
 CASES = [(127, None), (127, "m2=2,c=1"), (521, "m2=4,c=2"), (9941, "m2=16,c=4"), (9941, "m2=64,c=8"), (13967, None), (44497, "m2=32,c=4"),
-         (400063, "m2=8,c=4"), (300007, "m2=8,c=4"), (300007, "m2=16,c=8"), (300007, "m2=4,c=2"), (216091, None), (600011, "m2=32,c=8"), (1200007, "m2=64,c=8")]
+         (400063, "m2=8,c=4"), (800283, "m2=8,c=2"), (300007, "m2=8,c=4"), (300007, "m2=16,c=8"), (300007, "m2=4,c=2"), (216091, None), (600011, "m2=32,c=8"), (1200007, "m2=64,c=8")]
 
 
 def Engine(*a, **k):

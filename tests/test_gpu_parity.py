@@ -40,6 +40,8 @@ SMALL_CASES = [
     (300007, "m2=2048"), (600011, "m2=2048"), (1200007, "m2=2048,c=4"), (2976221, "m2=2048"), (4800007, "m2=2048,c=4"),
     # columns of 1280 = 5 x 256 on the register-resident radix-5 kernels (640 threads per tile), generic and radix-8 rows
     (400063, "m2=8,c=4"), (800283, "m2=16,c=4"), (1600589, "m2=32,c=4"),
+    # columns of 2560 = 5 x 512 with runs of two pairs on the same kernels (round 4: the columns of n = 5 2^22 and 5 2^23)
+    (800283, "m2=8,c=2"), (1600589, "m2=16,c=2"), (3200123, "m2=32,c=2"),
     # rows of 8192 (two 4096-point halves under one radix-2 level, 1024 threads)
     (300007, "m2=8192"), (600011, "m2=8192"), (1200007, "m2=8192,c=2"),
     # the split column sweeps of n = 5 * 2^26 (radix-5 stage through memory, power-of-two part in LDS) forced at small 5 * 2^k sizes:

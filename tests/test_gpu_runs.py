@@ -106,7 +106,7 @@ def test_an_injected_error_is_caught_when_the_blocks_run_as_single_calls():
         assert r["is_prime"] and r["gerbicz_errors"] == 1 and any("Check FAILED" in m for m in msgs)
 
 
-@pytest.mark.parametrize("p,plan", [(57885161, None), (205271257, None), (1600589, "m2=32,c=4"), (3200123, "m2=8,split5")])
+@pytest.mark.parametrize("p,plan", [(57885161, None), (205271257, None), (1600589, "m2=32,c=4"), (1600589, "m2=16,c=2"), (3200123, "m2=8,split5")])
 def test_runs_of_squarings_on_the_register_resident_and_split_paths(p, plan):
     """square_mul_n where it is the loop of launches (every shape the one-launch kernel does not serve): same digits as the loop of
     square_mul / sub calls, PRP and Lucas-Lehmer forms, pending subtraction carried across the calls"""

@@ -1,12 +1,13 @@
 #!/bin/bash
-# round 4: back + front in one launch for runs of squarings on the small shapes -- parity (square_mul_n against the oracle and the loop),
-# PRP driver tests (they run their blocks through square_mul_n), A/B against MI355_TUNE=4096 (chain off), complete PRP of M9815459
+# round 4 (second session): columns of 2560 = 5 x 512 with runs of two pairs on the radix-5 kernels -- parity cases, then same-box A/B at
+# n = 5 2^22 (new 2560 x 4096 against the old 1280 x 8192) and n = 5 2^23 (register-resident against generic columns)
 set -o pipefail
-O=gpurun_out/r04
+O=$GRAFT_REPO_ROOT/gpurun_out/r04b
 mkdir -p $O
-python -m pytest tests/test_gpu_runs.py tests/test_prp_driver.py tests/test_gpu_parity.py -x -q -m gpu > $O/job14_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/job14_tests.log
-run() { MI355_TUNE=$1 python bench.py --exponent $2 --no-cpu-baseline --steps 3000 --warmup 300 2>/dev/null | python -c "
+cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fused_ops.py tests/test_gpu_runs.py -m gpu -x -q -k "800283 or 1600589 or 3200123 or largest_supported or 400063" > $O/job14_pytest.log 2>&1; rc=$?; tail -5 $O/job14_pytest.log; [ $rc -ne 0 ] && exit $rc
+b() { timeout -k 10 300 python bench.py --exponent $1 ${2:+--plan $2} --no-cpu-baseline --steps 300 --warmup 20 --preheat-seconds 1 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms']
-print('tune=$1', $2, d['config']['plan'], d['ms_per_step'], 'll', d['ll_ms_per_step'], {a:round(b*1e3,1) for a,b in k.items() if a in ('k_front','k_middle','k_back')})"; }
-for rep in 1 2 3; do run 0 9815459; run 4096 9815459; run 0 19000013; run 4096 19000013; done > $O/job14_ab_chain.txt 2>&1; cat $O/job14_ab_chain.txt
-python tools/full_prp.py 9815459 2>&1 | tee $O/job14_c2_full_prp.txt | tail -2
+print($1, d['config']['plan'], d['ms_per_step'], {a:round(b*1e3,1) for a,b in k.items() if b>0}, 'frac', d['roofline']['iteration']['frac'])"; }
+{ for r in 1 2; do b 332000003; b 332000003 m2=8192; done; for r in 1 2; do b 700000001; MI355_KERNELS=v2rows b 700000001; done; b 205271257; } > $O/job14_ab.txt 2>&1
+cat $O/job14_ab.txt

@@ -1,7 +1,11 @@
 #!/bin/bash
-# round 4: complete PRP of the Mersenne prime M20996011 (n = 2^20) on the kernels of this round (radix-4 columns of 256 x 4 with one plane
-# per thread + rows of 2048 with one plane per thread), Gerbicz-Li check on
+# round 4 (second session): tile order of the 2560 x 2 front sweep again, after XCD-contiguous became its default (MI355_TUNE=32 now = plain order)
 set -o pipefail
-O=gpurun_out/r04
+O=$GRAFT_REPO_ROOT/gpurun_out/r04b
 mkdir -p $O
-timeout -k 10 1150 python tools/full_prp.py 20996011 2>&1 | tee $O/job18_m20996011_prp.txt | tail -4
+cd $GRAFT_REPO_ROOT
+b() { timeout -k 10 300 python bench.py --exponent $1 ${2:+--plan $2} --no-cpu-baseline --steps 300 --warmup 20 --preheat-seconds 1 2>/dev/null | python -c "
+import json,sys,os; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms']
+print('tune=%s' % os.environ.get('MI355_TUNE','0'), $1, d['config']['plan'], d['ms_per_step'], {a:round(b*1e3,1) for a,b in k.items() if b>0}, 'frac', d['roofline']['iteration']['frac'])"; }
+{ for r in 1 2 3; do b 332000003; MI355_TUNE=32 b 332000003; done; b 332000003 m2=8192; b 700000001; MI355_TUNE=32 b 700000001; } > $O/job18_ab.txt 2>&1
+cat $O/job18_ab.txt
