@@ -237,7 +237,7 @@ def test_edge_values():
             e.square_mul(2)              # a multiplicand is not a residue
 
 
-@pytest.mark.parametrize("p", [9815459, 19000013, 50000017, 100000007, 136279841, 205271257])
+@pytest.mark.parametrize("p", [9815459, 19000013, 50000017, 100000007, 136279841, 205271257, 250000013, 332000003])
 def test_extreme_digits_full_size(p):
     """Every digit at its maximum (x = Mp - 1 = -1: the largest convolution sums and the longest carry chains the transform can see) at the
     full-size shapes of every register-resident kernel set: (-1)^2 = 1, (-1)^2 * 3 = 3, then 3^2 - 2 through the deferred subtraction; digit
