@@ -120,6 +120,14 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
       dp_.F0f = f0_; dp_.F0i = f0_ + nt; dp_.FBf = f0_ + 2 * nt; dp_.FBi = f0_ + 2 * nt + pl_.M2;
     }
 #if defined(MI355_EXPERIMENTAL)
+    {
+      // back sweep + next front sweep in one launch for runs of squarings (kernels_v2.hip k31_cols): opt-in, MI355_CHAIN=1
+      const char* ch = std::getenv("MI355_CHAIN");
+      if (v2cols_ && ch && ch[0] == '1' && v2_chain_supported(dp_)) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&xchain_), pl_.runs() * 8 + 64));
+        HIPCHK(hipMemsetAsync(xchain_, 0, pl_.runs() * 8 + 64, stream_));
+      }
+    }
     if (v2rows_ && v2cols_) chain_tiles_ = v3_chain_tiles(dp_, device_);
     if (chain_tiles_) {
       HIPCHK(hipMalloc(reinterpret_cast<void**>(&chain_x_), size_t(chain_tiles_) * 256 * 8));
@@ -171,6 +179,7 @@ Engine::~Engine() {
   if (split_) (void)hipFree(split_);
   if (canon_) (void)hipFree(canon_);
 #if defined(MI355_EXPERIMENTAL)
+  if (xchain_) (void)hipFree(xchain_);
   if (chain_x_) (void)hipFree(chain_x_);
   if (chain_flags_) (void)hipFree(chain_flags_);
 #endif
@@ -199,6 +208,14 @@ void Engine::sync() {
 // The fused back + front launches of square_mul_n hand carry words from tile to tile inside the launch; a wait that timed out raised the
 // error word and left garbage behind: nothing is read out of the engine after that.
 void Engine::chain_check() {
+  if (xchain_failed_) throw std::runtime_error("chained squaring kernel: a carry hand-over timed out earlier; the engine's registers are not valid");
+  if (xchain_used_) {
+    uint32_t err = 0;
+    HIPCHK(hipMemcpyAsync(&err, xchain_err(), 4, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    xchain_used_ = false;
+    if (err) { xchain_failed_ = true; throw std::runtime_error("chained squaring kernel: carry hand-over timed out"); }
+  }
   if (chain_failed_) throw std::runtime_error("chained squaring kernel: a carry hand-over timed out earlier; the engine's registers are not valid");
   if (!chain_used_) return;
   uint32_t err = 0;
@@ -579,6 +596,21 @@ void Engine::square_mul_n(size_t r, uint32_t a, size_t count, uint32_t sub) {
   if (coop_groups_ && pending_sub_[r] < (1u << 30) && sub < (1u << 30)) { coop_launch(r, a, count, sub); return; }
 #endif
 #if defined(MI355_EXPERIMENTAL)
+  if (xchain_ && a == 1 && count >= 2 && sub < (1u << 30) && !xchain_failed_) {
+    // front | rows | [back + front | rows] x (count - 1) | back: the back sweep of a squaring and the front sweep of the next one are ONE
+    // launch (kernels_v2.hip k31_cols); same digits as the loop below
+    run_front(r);                                      // consumes pending carries / subtraction
+    for (size_t i = 0; i + 1 < count; ++i) {
+      run_middle(work(), nullptr, work(), 0, 0);
+      HIPCHK(v2_launch_backfront(dp_, work(), sub, xchain_, xchain_err(), xchain_tag_, stream_));
+      xchain_tag_ = xchain_tag_ % 4095u + 1u;          // 1 .. 4095: never the tag of the launch before, never the zero of a fresh buffer
+      xchain_used_ = true;
+    }
+    run_middle(work(), nullptr, work(), 0, 0);
+    run_back(r, a);
+    if (sub) sub_u32(r, sub);
+    return;
+  }
   if (chain_tiles_ && count >= 2 && sub < (1u << 30) && !chain_failed_) {
     // front | rows | [back + front | rows] x (count - 1) | back: the back sweep of a squaring and the front sweep of the next one are ONE
     // launch on the small shapes (kernels_v3.hip k31_cols256_planes); same digits as the loop below
@@ -830,11 +862,12 @@ void Engine::time_square_mul(size_t r, uint32_t a, uint32_t sub, size_t iters, d
   } else
 #endif
   {
+    bool as_run = false;   // the run of squarings as the callers issue it (experimental build: back + front in one launch where that is on)
 #if defined(MI355_EXPERIMENTAL)
-    if (chain_tiles_) square_mul_n(r, a, iters, sub);   // the run of squarings as the callers issue it (back + front in one launch on the small shapes)
-    else
+    as_run = xchain_ != nullptr || chain_tiles_ != 0;
 #endif
-    for (size_t i = 0; i < iters; ++i) {
+    if (as_run) square_mul_n(r, a, iters, sub);
+    else for (size_t i = 0; i < iters; ++i) {
       square_chain(r, a, nullptr);
       if (sub) sub_u32(r, sub);
     }

@@ -136,6 +136,13 @@ class Engine {
   uint64_t* chain_x_ = nullptr;
   uint32_t* chain_flags_ = nullptr;
   bool chain_used_ = false, chain_failed_ = false;
+  // runs of squarings with back + front in one launch on the radix-8 column shapes (kernels_v2.hip k31_cols; square_mul_n, MI355_CHAIN=1):
+  // hand-over words (one per run; null: not served / off) + the error word behind them, tag of the next launch, whether a launch is still
+  // unchecked / has failed
+  uint64_t* xchain_ = nullptr;
+  uint32_t xchain_tag_ = 1;
+  bool xchain_used_ = false, xchain_failed_ = false;
+  uint32_t* xchain_err() const { return reinterpret_cast<uint32_t*>(xchain_ + pl_.runs()); }
   void chain_check();   // throws when a hand-over wait of an earlier launch timed out (the registers are not valid then)
 #else
   void chain_check() {}

@@ -76,6 +76,11 @@ hipError_t v2_launch_middle(const DevPlan& pl, const uint64_t* Win, const uint64
 hipError_t v2_launch_front(const DevPlan& pl, const uint32_t* digits, const uint64_t* cbuf_in, uint32_t sub, uint64_t* W, hipStream_t s);
 hipError_t v2_launch_back(const DevPlan& pl, const uint64_t* W, uint32_t* digits, uint64_t* cbuf, uint32_t a, uint64_t scale, hipStream_t s);
 #if defined(MI355_EXPERIMENTAL)
+// runs of squarings on the radix-8 column shapes (kernels_v2.hip k31_cols): the back sweep of one squaring and the front sweep of the next in one
+// launch (a = 1).  xbuf: one hand-over word per run (tiles x M1), err: the error word a timed-out wait raises, tag: 1 .. 4095, different from
+// the previous launch's on the same xbuf
+bool v2_chain_supported(const DevPlan& pl);
+hipError_t v2_launch_backfront(const DevPlan& pl, uint64_t* W, uint32_t sub, uint64_t* xbuf, uint32_t* err, uint32_t tag, hipStream_t s);
 // runs of squarings on the small shapes (kernels_v3.hip): the back sweep of one squaring and the front sweep of the next in one launch.
 // v3_chain_tiles: tiles of such a launch (all resident at once on `device`), 0 where the plan is not served.  xbuf: tiles x 256 carry
 // words, flags: tiles + 1 words (the last one is the error word a timed-out wait raises), epoch: larger than any used before on these flags

@@ -754,6 +754,80 @@ __global__ void __launch_bounds__(512, 4) k3_cols_ext(DevPlan pl, const uint64_t
   }
 }
 
+#if defined(MI355_EXPERIMENTAL)
+// ---------------------------------------------------------------------------------------------
+// Back sweep of squaring i and front sweep of squaring i + 1 in ONE launch (round 4, second session; Engine::square_mul_n with MI355_CHAIN=1,
+// experimental build only).
+// Between the two sweeps everything is local to a column tile -- the thread that ends the back sweep with the digits of its R runs is the
+// thread that starts the front sweep with them -- except the carry word of the PREVIOUS run in digit order, which the neighbouring tile
+// T - 1 produces (reference: carry_weight_mul_p1 / p2 hand it through a carry array and a second kernel, kernels/marin.cl:1696-1728,2198-2216).
+// Hand-over inside the launch, one 64-bit word per run: {tag of the launch (12 bits) | carry (52 bits)}, stored and polled with agent-scope
+// accesses (past the XCD's non-coherent L2) by the two threads concerned: the word is its own flag, nothing else has to be ordered.
+// No cycle and no wait on a group that is not yet dispatched:
+//   * tiles are taken in the XCD-contiguous order of the back sweep (block b -> XCD b mod 8, tile (b & 7) NT / 8 + (b >> 3)), so the tile a
+//     group waits for belongs to the block dispatched just before it on the SAME XCD;
+//   * the first block of every XCD (b < 8), whose predecessor tile is the last one of another XCD's range (or, for tile 0, the last tile of
+//     all: 2^p = 1), only runs the back sweep and publishes its carries; eight extra blocks at the end of the grid (b = NT + x, again on
+//     XCD x) run that tile in full: by then the tile they wait for is resident or done.  Cost: eight half tiles in 1024.
+// The digits themselves are not stored inside a run of squarings (the last squaring of a run goes through the plain back sweep).
+// MEASURED (profiles/r04_ab_chain_backfront.txt, same box): C3 0.1426 -> 0.1445 ms (+1.4 %), n = 2^22 +4 %, 2^21 +5 %, 2^24 +13 %: a group
+// now lives twice as long, so the end of the launch (CUs left with one late group) costs twice as much, and the waits come on top; the kernel
+// boundary it replaces costs less.  Not in the product library: built only with -DMI355_EXPERIMENTAL (make exp), parity-checked there
+// (tools/exp_coop_check.py; 6 GPU cases incl. C3 passed on the product build before it was moved).
+// A wait that outlasts kChainTimeoutTicks (100 MHz: 50 ms) raises the error word -- the engine refuses every later read-out -- and goes on
+// with a zero carry, so that the grid always drains.
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t kChainTimeoutTicks = 5000000ull;
+constexpr uint32_t kChainTagShift = 52;
+
+template <int R>
+__global__ void __launch_bounds__(512, 4) k31_cols(DevPlan pl, uint64_t* __restrict__ Wbuf, uint32_t sub, uint64_t* __restrict__ xbuf, uint32_t* __restrict__ err, uint32_t tag) {
+  using S = ColShape<R>;
+  P2* X = reinterpret_cast<P2*>(smem_v2);
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t NT = pl.M2 / pl.C, per = NT >> 3, b = blockIdx.x;
+  const bool extra = b >= NT;                                  // second visit of the first tile of an XCD's range: the full job
+  const bool publish_only = b < 8;                             // first visit: back sweep + publish
+  const uint32_t T = extra ? (b - NT) * per : (b & 7) * per + (b >> 3);
+  if (b >= pl.boost_tiles) __builtin_amdgcn_s_setprio(3);
+  uint32_t dg[R][16 / R];
+  uint64_t cout[R], zero[R];
+  const uint32_t di = pl.DI[size_t(T) * 512 + t];
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1) zero[d1] = 0;
+  back_tile<R>(pl, X, T, t, lane, wave, Wbuf, 1u, 1, zero, di, dg, cout);
+#pragma unroll
+  for (int d1 = 0; d1 < R; ++d1)
+    __hip_atomic_store(&xbuf[size_t(T) * S::M1 + 512 * d1 + t], (uint64_t(tag) << kChainTagShift) | cout[d1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (publish_only) return;
+  // the carries of the previous runs in digit order (carry_in_of): same row of tile T - 1; tile 0 wraps to the last tile of the previous row
+  {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t cin[R];
+    bool ok = true;
+#pragma unroll
+    for (int d1 = 0; d1 < R; ++d1) {
+      const uint32_t i1 = 512 * d1 + t;
+      const uint64_t* src = &xbuf[T ? size_t(T - 1) * S::M1 + i1 : size_t(NT - 1) * S::M1 + (i1 ? i1 - 1 : S::M1 - 1)];
+      uint64_t v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t spins = 0;
+      while (uint32_t(v >> kChainTagShift) != tag) {
+        if ((++spins & 15u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kChainTimeoutTicks) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+        v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      cin[d1] = ok ? (v & ((uint64_t(1) << kChainTagShift) - 1)) : 0;
+    }
+    if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int d1 = 0; d1 < R; ++d1) apply_carry_in<16 / R>(pl, di, d1, cin[d1], dg[d1]);
+  }
+  asm volatile("" ::: "memory");   // the front sweep's table loads stay behind the wait (hoisted into the back sweep they cost registers: spills)
+  front_tile<R>(pl, X, T, t, lane, wave, dg, di, sub, Wbuf);
+}
+
+#endif   // MI355_EXPERIMENTAL
+
 }  // namespace v2
 
 namespace v2 {
@@ -829,6 +903,9 @@ hipError_t v2_configure() {
   MI355_SET_LDS(v2::k3_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols<4>, v2::kLdsBytes)
   { hipError_t e5 = v5_configure(); if (e5 != hipSuccess) return e5; }
   MI355_SET_LDS(v2::k3_cols_ext<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols_ext<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k3_cols_ext<4>, v2::kLdsBytes)
+#if defined(MI355_EXPERIMENTAL)
+  MI355_SET_LDS(v2::k31_cols<1>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<2>, v2::kLdsBytes) MI355_SET_LDS(v2::k31_cols<4>, v2::kLdsBytes)
+#endif
   return hipSuccess;
 }
 #undef MI355_SET_LDS
@@ -884,6 +961,24 @@ hipError_t v2_launch_back_ext(const DevPlan& pl, const uint64_t* W, uint32_t* di
   }
   return hipGetLastError();
 }
+
+#if defined(MI355_EXPERIMENTAL)
+// back + front in one launch (k31_cols): served where the power-of-two column kernels run on at least 16 tiles, a multiple of 8, and a run
+// carry fits the 52 bits of a hand-over word (a = 1: carry < 2^(64 - q))
+bool v2_chain_supported(const DevPlan& pl) {
+  const uint32_t NT = pl.M2 / pl.C;
+  return v2_cols_supported(pl) && !v5_cols_shape(pl) && !v3_cols_shape(pl) && NT % 8 == 0 && NT >= 16 && pl.q >= 13;
+}
+hipError_t v2_launch_backfront(const DevPlan& pl, uint64_t* W, uint32_t sub, uint64_t* xbuf, uint32_t* err, uint32_t tag, hipStream_t s) {
+  const dim3 grid(pl.M2 / pl.C + 8), block(512);
+  switch (pl.M1) {
+    case 512: hipLaunchKernelGGL(v2::k31_cols<1>, grid, block, v2::kLdsBytes, s, pl, W, sub, xbuf, err, tag); break;
+    case 1024: hipLaunchKernelGGL(v2::k31_cols<2>, grid, block, v2::kLdsBytes, s, pl, W, sub, xbuf, err, tag); break;
+    default: hipLaunchKernelGGL(v2::k31_cols<4>, grid, block, v2::kLdsBytes, s, pl, W, sub, xbuf, err, tag); break;
+  }
+  return hipGetLastError();
+}
+#endif
 
 #if defined(MI355_PROBE)
 size_t v2_lds_bytes() { return v2::kLdsBytes; }
