@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   // plane a of every row unchanged
   if (H == 1) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = in[512 * j + t];
+    for (int j = 0; j < 8; ++j) x[j] = w_load(&in[512 * j + t]);
     if (sub != 0 && t == 0) {
 #pragma unroll
       for (int r = 0; r < (1 << RL); ++r) x[R1 * r].a = gf::sub(x[R1 * r].a, uint64_t(sub));   // element 0 of every row of the tile
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) out[512 * j + t] = x[j];
+  for (int j = 0; j < 8; ++j) w_store(&out[512 * j + t], x[j]);
   PROBE_END(pl)
 }
 
@@ -561,7 +561,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t rj = ((j & 1) << 2) | (j & 2) | (j >> 2);   // bitrev3(j)
-      W[size_t(row0 + rj) * pl.M2 + i2] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)};
+      w_store(&W[size_t(row0 + rj) * pl.M2 + i2], P2{gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)});
       if (j < 7) ca = gf::mul(ca, B);
     }
   }
@@ -592,7 +592,7 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t rj = ((j & 1) << 2) | (j & 2) | (j >> 2);
-      x[j] = W[size_t(row0 + rj) * pl.M2 + i2];
+      x[j] = w_load(&W[size_t(row0 + rj) * pl.M2 + i2]);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -30,6 +30,26 @@ constexpr uint32_t kLdsSlots = 4096;
 #endif
 constexpr uint32_t kLdsBytes = kLdsSlots * 16;
 
+// Work-buffer accesses of the sweeps.  -DMI355_NT=<bits> (A/B builds only): bit 0 stores, bit 1 loads with the non-temporal hint (streamed
+// through L2: a sweep never re-reads what it wrote and the next launch reads it from the memory side anyway).
+typedef uint64_t u64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void w_store(P2* p, P2 v) {
+#if defined(MI355_NT) && (MI355_NT & 1)
+  u64x2_t q; q.x = v.a; q.y = v.b;
+  __builtin_nontemporal_store(q, reinterpret_cast<u64x2_t*>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ P2 w_load(const P2* p) {
+#if defined(MI355_NT) && (MI355_NT & 2)
+  const u64x2_t q = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(p));
+  return {q.x, q.y};
+#else
+  return *p;
+#endif
+}
+
 __device__ __forceinline__ P2 p2_mul(P2 x, uint64_t w) { return {gf::mul(x.a, w), gf::mul(x.b, w)}; }
 
 template <bool INV, int LAZY = 0>
