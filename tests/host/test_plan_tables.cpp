@@ -10,7 +10,9 @@ static bool wrap_of(uint64_t sa, uint64_t sb, uint64_t n) { return sa > 0 && sb 
 int main() {
   struct Case { uint32_t p; const char* spec; };
   const Case cases[] = {{127, nullptr}, {9941, nullptr}, {3997, nullptr}, {300007, "m2=8,c=4"}, {300007, "m2=16,c=8"},
-                        {300007, "m2=4,c=2"}, {600011, "m2=32,c=8"}, {102701, nullptr}};
+                        {300007, "m2=4,c=2"}, {600011, "m2=32,c=8"}, {102701, nullptr},
+                        {132049, "m2=16,c=4"},                              // columns of 256 x 4 (kernels_v3.hip: 256 threads, one run each)
+                        {400063, "m2=8,c=4"}, {800283, "m2=8,c=2"}};        // radix-5 columns 1280 x 4 and 2560 x 2 (kernels_v5.hip: 640 threads, runs i1 = t + 640 d1)
   int bad = 0;
   for (const Case& cs : cases) {
     const Plan pl = make_plan(cs.p, cs.spec, true);
@@ -37,8 +39,9 @@ int main() {
         if (bad++ < 5) printf("inverse p=%u j=%llu\n", cs.p, (unsigned long long)j);
       }
       if (!pl.DI.empty()) {
-        const uint32_t C = pl.C, ND = 2 * C, T = uint32_t(i2 / C), c = uint32_t(i2 % C), t = uint32_t(i1 % 512), d1 = uint32_t(i1 / 512);
-        const uint32_t bits = (pl.DI[size_t(T) * 512 + t] >> (2 * (d1 * ND + 2 * c + b))) & 3u;
+        const uint32_t TP = (pl.r5 == 5) ? 640u : (pl.M1 == 256 ? 256u : 512u);   // threads per tile of the kernel set that reads the words
+        const uint32_t C = pl.C, ND = 2 * C, T = uint32_t(i2 / C), c = uint32_t(i2 % C), t = uint32_t(i1 % TP), d1 = uint32_t(i1 / TP);
+        const uint32_t bits = (pl.DI[size_t(T) * TP + t] >> (2 * (d1 * ND + 2 * c + b))) & 3u;
         if ((bits & 1u) != width - pl.q || ((bits >> 1) != 0) != wr2) { if (bad++ < 5) printf("DI p=%u j=%llu\n", cs.p, (unsigned long long)j); }
         ++di_checked;
       }

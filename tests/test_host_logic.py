@@ -37,6 +37,17 @@ def test_plan_policy_matches_reference_sizes():
         assert m1 * m2 * 2 == n and m2 % c == 0 and lf <= 160 * 1024 and lm <= 160 * 1024
 
 
+def test_plan_policy_of_the_sizes_beyond_rows_of_4096():
+    """columns of 2560 = 5 x 512 keep the rows of n = 5 2^22 at 4096 (round 4); from 2^25 on the rows are 8192 wide; n = 5 2^26 takes the split sweeps"""
+    from prmers_amd import resolve_plan
+    want = {205271257: "n=10485760:m1=1280:m2=4096:c=4", 250000013: "n=16777216:m1=2048:m2=4096:c=2", 332000003: "n=20971520:m1=2560:m2=4096:c=2",
+            600000001: "n=33554432:m1=2048:m2=8192:c=2", 700000001: "n=41943040:m1=2560:m2=8192:c=2", 1300000003: "n=83886080:m1=5120:m2=8192:c=2",
+            4000000007: "n=335544320:m1=20480:m2=8192:c=1:split5"}
+    for p, plan in want.items():
+        assert resolve_plan(p) == "marin-hip:" + plan, (p, resolve_plan(p))
+    assert resolve_plan(332000003, "m2=8192") == "marin-hip:n=20971520:m1=1280:m2=8192:c=4"   # the round-3 plan stays selectable
+
+
 def test_plan_weight_tables_and_digit_info_words():
     """plan.hpp: digit widths, both factorisations of the IBDWT weights (incl. the second half of SA/TA used
     for odd digits), the inverse tables and the 2-bit-per-digit DI words, digit by digit against the defining
@@ -44,6 +55,8 @@ def test_plan_weight_tables_and_digit_info_words():
     out = _build_and_run("test_plan_tables.cpp")
     assert out.strip().endswith("OK"), out
     assert "di_checked=16384" in out and "di_checked=32768" in out   # the register-resident column shapes were covered
+    assert "m1=256:m2=16:c=4 digits=8192 di_checked=8192" in out       # radix-4 columns
+    assert "m1=1280:m2=8:c=4 digits=20480 di_checked=20480" in out and "m1=2560:m2=8:c=2 digits=40960 di_checked=40960" in out   # radix-5 columns
 
 
 def test_c_abi_exports_and_no_gpu_behaviour():
