@@ -244,6 +244,21 @@ def test_full_prp_of_m216091_on_gpu():
     assert r["complete"] and r["is_prime"] and r["res64"] == "0000000000000001" and r["gerbicz_errors"] == 0
 
 
+@pytest.mark.gpu
+def test_prp_blocks_of_m859433_on_the_radix5_columns_of_2560():
+    """the Mersenne prime exponent 859433 (n = 5 2^13) with the transform forced onto the columns of 2560 = 5 x 512 with runs of two pairs
+    (kernels_v5.hip, J = 1: the column kernels of n = 5 2^22 and 5 2^23): the first 150 000 squarings of its PRP with the Gerbicz-Li check on,
+    an injected error caught and repaired on the way.  (The complete PRP -- 859433 squarings, residue 9, one injected error repaired -- ran
+    on the same kernels in 73 s: profiles/r04_soak_c.txt.)"""
+    from prmers_amd import Engine
+    p = 859433
+    with Engine(p, prp.REGISTERS, plan="m2=8,c=2") as e:
+        assert e.describe().startswith("marin-hip:n=40960:m1=2560:m2=8:c=2")
+        msgs = []
+        r = prp.run_prp_or_ll(e, p, "prp", checklevel=1, max_iters=150000, erroriter=60000, log=msgs.append)
+    assert r["gerbicz_errors"] == 1 and r["gerbicz_checks"] >= 2 and any("Check FAILED" in m for m in msgs), msgs[-5:]
+
+
 def test_result_json_shape():
     """keys and order of the reference's PRP / LL result JSON (src/io/JsonBuilder.cpp:396-441)."""
     with orc.OracleEngine(127, prp.REGISTERS) as e:
