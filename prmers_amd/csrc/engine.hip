@@ -111,6 +111,8 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     const std::string sel = ks ? ks : "v2";
     v2rows_ = (sel == "v2" || sel == "v2rows") && v2_rows_supported(dp_);
     v2cols_ = (sel == "v2" || sel == "v2cols") && v2_cols_supported(dp_);
+    dp_.lab_u = 1; dp_.lab_v = pl_.r5;
+    if (v2cols_ && v5_cols_shape(dp_)) v5_pfa(dp_, &dp_.lab_u, &dp_.lab_v);   // radix-5 columns in prime-factor form: their own frequency labels
     if (v2rows_ || v2cols_) HIPCHK(v2_configure());
     if (v2cols_) {   // four-step chain starts and ratios: built once on the device (2 x tiles x 512 + 2 x M2 words)
       const size_t nt = pl_.tiles() * v2_threads_per_tile(dp_);

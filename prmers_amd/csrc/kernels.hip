@@ -71,7 +71,7 @@ __device__ __forceinline__ uint64_t tw_lookup(const DevPlan& pl, uint64_t e) {
 __device__ __forceinline__ uint32_t freq1(const DevPlan& pl, uint32_t pos) {
   const uint32_t blk = pos >> pl.logL1, q = pos & (pl.L1 - 1);   // L1 is a power of two
   const uint32_t rq = pl.logL1 ? (__brev(q) >> (32 - pl.logL1)) : 0u;
-  return blk + pl.r5 * rq;
+  return col_label(pl, blk, rq);
 }
 
 // p*j mod n for digit (i1, x = 2*i2+b), its width, and whether the factored weight wrapped
@@ -362,7 +362,7 @@ __device__ __forceinline__ void middle_body(const DevPlan& pl, const uint64_t* W
   const bool one = M2 <= nthr;   // one element per thread: its twiddle words are requested before the transform (see k_front)
   uint64_t pre_lo = 0, pre_hi = 0;
   if (one && tid < M2 && mode != 2) {
-    const uint64_t ex = uint64_t(k1) + uint64_t(pl.M1) * (__brev(tid) >> (32 - pl.logM2));
+    const uint64_t ex = rho_exponent(pl, k1, __brev(tid) >> (32 - pl.logM2));
     pre_lo = pl.TWlo[ex & ((1u << pl.twh) - 1)]; pre_hi = pl.TWhi[ex >> pl.twh];
   }
   lds_pow2_dft<false>(X, M2, pl.logM2, 1, 1, 0, pl.UT2, M2, 1, pl.I4, tid, nthr);
@@ -373,7 +373,7 @@ __device__ __forceinline__ void middle_body(const DevPlan& pl, const uint64_t* W
   const P2* Y = reinterpret_cast<const P2*>(Yimg) + size_t(row) * M2;
   for (uint32_t e = tid; e < M2; e += nthr) {
     const uint32_t k2 = __brev(e) >> (32 - pl.logM2);
-    const uint64_t rho = one ? gf::mul(pre_lo, pre_hi) : tw_lookup(pl, uint64_t(k1) + uint64_t(pl.M1) * k2);
+    const uint64_t rho = one ? gf::mul(pre_lo, pre_hi) : tw_lookup(pl, rho_exponent(pl, k1, k2));
     const P2 u = X[e];
     P2 r;
     if (mode == 0) {  // (u0 + u1 t)^2 mod (t^2 - rho), marin.cl:379-384

@@ -16,12 +16,27 @@ struct DevPlan {
   const uint64_t *F0f, *F0i, *FBf, *FBi;   // four-step chain starts [tile][thread] and ratios [column] of the v2 column kernels
   const uint32_t* DI;   // digit-info words of the v2 column kernels: [tile][thread] 16 x (width - q, wrap), or null
   uint32_t boost_rows, boost_tiles;   // first block index of the last half round of the row / column launches (or ~0u)
+  // Frequency label of the column-transform output slot (blk, rq): lab_u blk + lab_v rq.  (1, r5) for the mixed-radix columns of every kernel
+  // set but one; the radix-5 columns in prime-factor form (kernels_v5.hip) hold the frequency (PU k0 + PV kr) mod M1 in slot (k0, kr) and the
+  // engine sets (PU, PV) when they run both column sweeps.  See col_label() below.
+  uint32_t lab_u, lab_v;
 #if defined(MI355_PROBE)
   uint64_t* probe;        // timeline probe (tools/probe.py, libmi355_engine_probe.so only): 8 words per work-group, or null
   uint32_t probe_mod;     // blockIdx.x is taken modulo this (launches of several rounds over the same tiles)
 #endif
   uint32_t tune;   // MI355_TUNE bit 0: plain (not XCD-contiguous) tile order in the back sweep, for A/B runs; bit 2: no issue-priority boost of the last half round
 };
+
+#if defined(__HIPCC__)
+// Frequency label of the column-transform output slot (blk, rq) -- rq the bit-reversed position inside the radix-5 block (kernels.hip freq1).
+// Every use of a column frequency k1 (the four-step twiddle omega_m^(i2 k1), the point rho = omega_m^(k1 + M1 k) of the pointwise stage) only
+// needs SOME integer congruent to it mod M1, the same one in the front sweep, the row sweep and the back sweep: a representative k1 + M1 s
+// shifts the row transform's outputs by s places and the total frequency k1 + M1 k2 stays what the label says.  The prime-factor columns use
+// PU blk + PV rq unreduced (< 2^20; their twiddle chains step through rq by constant ratios); the two-level root table reaches m + 2^20.
+__device__ __forceinline__ uint32_t col_label(const DevPlan& pl, uint32_t blk, uint32_t rq) { return pl.lab_u * blk + pl.lab_v * rq; }
+// exponent of rho = omega_m^(label + M1 k): below m + 2^20 (plan.hpp TWhi)
+__device__ __forceinline__ uint64_t rho_exponent(const DevPlan& pl, uint32_t label, uint64_t k) { return uint64_t(label) + uint64_t(pl.M1) * k; }
+#endif
 
 // Extras of a back sweep (the reference's fused carry variants, kernels/marin.cl:2160-2365):
 //   digits2 / cbuf2: a second register that receives the same result (square_mul_copy, mul_copy)
@@ -64,6 +79,11 @@ hipError_t launch_back_split(const DevPlan& pl, const uint64_t* W, uint64_t* U, 
 hipError_t launch_addsub(const DevPlan& pl, uint32_t* dst, const uint32_t* src, uint64_t* cbuf, int negate, hipStream_t s);
 hipError_t launch_sub_small(const DevPlan& pl, uint32_t* digits, uint32_t a, hipStream_t s);
 
+
+// radix-5 column shapes of kernels_v5.hip (M1 = 1280 = 5 x 256 with C = 4, M1 = 2560 = 5 x 512 with C = 2) and the frequency map of their
+// prime-factor form (DevPlan.lab_u / lab_v)
+inline bool v5_cols_shape(const DevPlan& pl) { return pl.r5 == 5 && ((pl.M1 == 1280 && pl.C == 4) || (pl.M1 == 2560 && pl.C == 2)) && pl.M2 >= 8; }
+void v5_pfa(const DevPlan& pl, uint32_t* u, uint32_t* v);
 
 // register-resident radix-8 set (kernels_v2.hip); shapes: rows M2 = 4096, columns M1 = 1024 x C = 4
 bool v2_rows_supported(const DevPlan& pl);

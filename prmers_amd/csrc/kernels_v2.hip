@@ -103,8 +103,8 @@ __global__ void __launch_bounds__(512 * H, 4) k2_rows4096(DevPlan pl, const uint
   // S4 thread (k3|k1|k2): frequency base k1 + 8 k2 + 64 k3 (several rows: k1' + R1 k2 + 8 R1 k3 with k1' = k1 & (R1 - 1))
   const uint32_t kb = ((lane >> 3) & uint32_t(R1 - 1)) + R1 * (lane & 7) + 8 * R1 * wave;
   const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;       // column-DFT slot -> frequency (kernels.hip freq1)
-  const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
-  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * (HH * kb + h);   // row frequency of X[kb]: H kb + h
+  const uint32_t k1row = col_label(pl, blk, pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+  const uint64_t erho = rho_exponent(pl, k1row, HH * kb + h);   // row frequency of X[kb]: H kb + h
   const uint64_t rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)], rho_hi = pl.TWhi[erho >> pl.twh];
 
   // ---- forward ----
@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(512, 4) k2_rows2048_planes(DevPlan pl, const u
   const uint32_t pln = lane >> 5, partner = ((lane ^ 32u) << 2);
   const uint32_t kb = ((lane >> 3) & 3u) + 4 * (lane & 7) + 32 * wave;
   const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;       // column-DFT slot -> frequency (kernels.hip freq1)
-  const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
-  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * kb;
+  const uint32_t k1row = col_label(pl, blk, pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+  const uint64_t erho = rho_exponent(pl, k1row, kb);
   const uint64_t rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)], rho_hi = pl.TWhi[erho >> pl.twh];
 
   // ---- forward ----

@@ -210,8 +210,7 @@ __device__ __forceinline__ void apply_carry_in(const DevPlan& pl, uint32_t di, i
 
 }  // namespace v2
 
-// radix-5 column shapes (M1 = 1280 = 5 x 256 with C = 4, M1 = 2560 = 5 x 512 with C = 2) and their launch entry points (kernels_v5.hip)
-inline bool v5_cols_shape(const DevPlan& pl) { return pl.r5 == 5 && ((pl.M1 == 1280 && pl.C == 4) || (pl.M1 == 2560 && pl.C == 2)) && pl.M2 >= 8; }
+// launch entry points of the radix-5 column shapes (kernels_v5.hip; v5_cols_shape, v5_pfa: kernels.hpp)
 size_t v5_threads_per_tile();
 hipError_t v5_configure();
 hipError_t v5_build_fourstep(const DevPlan& pl, uint64_t* f0f, uint64_t* f0i, uint64_t* fbf, uint64_t* fbi, hipStream_t s);

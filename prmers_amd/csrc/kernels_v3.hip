@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(kThreads) k2_rows1024(DevPlan pl, const uint64
   // rho0 = omega_m^(k1row + M1 kb): row frequency of the thread's register 0 after S5 (kernels.hip freq1 for the row's own frequency)
   const uint32_t kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t) + 64 * (t & 3u);
   const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;
-  const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
-  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * kb;
+  const uint32_t k1row = col_label(pl, blk, pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+  const uint64_t erho = rho_exponent(pl, k1row, kb);
   uint64_t rho_lo = 0, rho_hi = 0;
   if (mode != 2) { rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)]; rho_hi = pl.TWhi[erho >> pl.twh]; }
 
@@ -232,8 +232,8 @@ __global__ void __launch_bounds__(2 * kThreads) k2_rows1024_planes(DevPlan pl, c
   }
   const uint32_t kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t) + 64 * (t & 3u);
   const uint32_t blk = row / pl.L1, qq = row - blk * pl.L1;
-  const uint32_t k1row = blk + pl.r5 * (pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
-  const uint64_t erho = uint64_t(k1row) + uint64_t(pl.M1) * kb;
+  const uint32_t k1row = col_label(pl, blk, pl.logL1 ? (__brev(qq) >> (32 - pl.logL1)) : 0u);
+  const uint64_t erho = rho_exponent(pl, k1row, kb);
   uint64_t rho_lo = 0, rho_hi = 0;
   if (mode != 2) { rho_lo = pl.TWlo[erho & ((1u << pl.twh) - 1)]; rho_hi = pl.TWhi[erho >> pl.twh]; }
   if (sub != 0 && threadIdx.x == 0) x[0] = gf::sub(x[0], uint64_t(sub));   // element 0, plane a

@@ -9,12 +9,13 @@ namespace mi355 {
 // Columns of M1 = 1280 = 5 x 256 (n = 5 * 2^21: BASELINE configs[3] on the Goldilocks path), C = 4 pairs per run: one tile
 // of 5120 pairs per work-group of 640 threads, 8 pairs per thread, the radix-5 stage on 512 threads with 10.
 // The reference serves this size with forward80_0 / backward80_0 (kernels/marin.cl:1019-1040, engine_gpu.h:1619).
-//   i1 = 256 d0 + r,  r = 64 e1 + 8 e2 + e3;  column frequency k = k0 + 5 kr,  kr = k1 + 4 k2 + 32 k3
+//   i1 = (256 d0 + 5 r) mod 1280 (prime-factor input map, round 4),  r = 64 e1 + 8 e2 + e3;  slot (k0, kr), kr = k1 + 4 k2 + 32 k3, holds the
+//   column frequency (256 k0 + 1025 kr) mod 1280 (Shape<J>::PU / PV; rounds 2-3: i1 = 256 d0 + r, frequency k0 + 5 kr, a twiddle after stage A)
 //   L   thread t: runs i1 = t, t + 640 (digits -> carry-in -> weight)
-//   A   thread u < 512: groups g = u, u + 512 (r = g / 4, c = g % 4): DFT5 over d0, twiddle omega_1280^(r k0)
+//   A   thread u < 512: groups g = u, u + 512 (r = g / 4, c = g % 4): DFT5 over d0 (no twiddle: 5 and 256 are coprime)
 //   B1  thread (k0 | e2 | e3 | c/2): DFT4 over e1, twiddle omega_256^(k1 (8 e2 + e3))
 //   B2  thread (k0 | k1 | e3 | c):   DFT8 over e2, twiddle omega_64^(k2 e3)
-//   B3  thread (k0 | k1 | k2 | c):   DFT8 over e3, then the four-step twiddle chain (ratio omega_m^(160 i2)) and the store to
+//   B3  thread (k0 | k1 | k2 | c):   DFT8 over e3, then the four-step twiddle chain (ratio omega_m^(1025 x 32 i2)) and the store to
 //       row k0 256 + bitrev8(kr), the row order of kernels.hip freq1
 // The factor 5 leaves no digit that is uniform over a wavefront, so the seams inside the power-of-two part are table
 // multiplications (omega_1280 powers from UT1) instead of the compile-time shifts of the 512 R shapes.  LDS carries one
@@ -30,8 +31,16 @@ constexpr uint32_t kThreads = 640, kTile = 5120;
 template <int J> struct Shape {
   static constexpr uint32_t C = 4u >> J, LC = 2 - J, L = 256u << J, M1 = 5 * L, R1 = 4u << J;   // pairs per run, log2 C, M1 / 5, radix of the e1 stage
   static constexpr uint32_t NR = 2u << J, ND = 2 * C, QW = ND / 4;                                // runs per thread, digits per run, uint4 per run
-  static constexpr int SA = 2, SB1 = 1, SB2 = J ? 3 : 1, SB3 = 3;                                   // LDS slot maps per exchange (tools/lds_census5.py)
+  static constexpr int SA = 2, SAb = J ? -1 : 5, SB1 = 1, SB2 = J ? 3 : 1, SB3 = 3;                 // LDS slot maps per exchange (tools/lds_census5.py); SAb: stage A of the back sweep
+  // Prime-factor form of the 5 x L split (Good-Thomas: 5 and L are coprime, so no twiddle stands between the radix-5 stage and the power-of-two
+  // part): input i1 = (L d0 + 5 r) mod M1, output slot (k0, kr) holds the frequency (PU k0 + PV kr) mod M1 with PU = L (L^-1 mod 5),
+  // PV = 5 (5^-1 mod L) = 1025 for L = 256 and 512.  The engine passes PU / PV to every kernel that needs a column frequency (DevPlan.lab_u/v,
+  // kernels.hpp col_label).  Saves the four table products per radix-5 butterfly and direction of the mixed-radix form: C4 front 56.3 -> 53.0 us, back 62.3 -> 58.2,
+  // 0.2000 -> 0.1925 ms per squaring; n = 5 2^20 -3 %, 5 2^22 -2.6 % (same-box A/B, profiles/r04_ab_pfa5.txt).
+  static constexpr uint32_t PU = J ? 1536u : 256u, PV = 1025u;
 };
+static_assert((Shape<0>::PU % 5) == 1 && (Shape<0>::PU % 256) == 0 && (Shape<0>::PV % 256) == 1 && (Shape<0>::PV % 5) == 0, "CRT idempotents, L = 256");
+static_assert((Shape<1>::PU % 5) == 1 && (Shape<1>::PU % 512) == 0 && (Shape<1>::PV % 512) == 1 && (Shape<1>::PV % 5) == 0, "CRT idempotents, L = 512");
 // Launched with 768 threads: twelve waves spread evenly over the four SIMDs of a CU, the last two leave at once.  A work-group of ten waves
 // (3 + 3 + 2 + 2) is not placed next to a resident one for up to 17 us after a slot has become free (profiles/r03_probe_c4.md: 44 % of
 // the dispatches of a launch, a CU then runs one group for half of its time); twelve are placed within 2 us like the 512-thread groups.
@@ -50,11 +59,12 @@ constexpr uint32_t lds_bytes(uint32_t m1) { return (kPlaneWords + m1) * 8; }
 // these kernels to bank conflicts (SQ_LDS_BANK_CONFLICT 4.03 M of SQ_LDS_IDX_ACTIVE 9.07 M per launch at C4: the last exchange of the front
 // and the first of the back were 4-way conflicted).  -DMI355_LDS_ADD3 restores it for A/B builds.
 template <int S>
-__device__ __forceinline__ uint32_t ph(uint32_t i) {
+__device__ __forceinline__ uint32_t ph(uint32_t i) {   // S < 0: identity
 #if defined(MI355_LDS_ADD3)
   return i + (i >> 5);
 #else
-  return i ^ ((i >> S) & 31u);
+  if constexpr (S < 0) return i;
+  else return i ^ ((i >> S) & 31u);
 #endif
 }
 template <uint32_t M1>
@@ -140,15 +150,12 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const 
   P2 y[10];
   exchange<8, 10, S::SA>(X, x, y, true, t < 512,
                   [&](int k) { return (t + kThreads * (uint32_t(k) >> LC)) * C + (uint32_t(k) & (C - 1)); },
-                  [&](int k) { return 1024u * (k % 5) + t + 512u * (k / 5); });
+                  [&](int k) { const uint32_t g = t + 512u * (k / 5); return ((L * (k % 5) + 5 * (g >> LC)) % M1) * C + (g & (C - 1)); });   // i1 = (L d0 + 5 r) mod M1
   if (t < 512) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const uint32_t r = (t + 512 * q) >> LC;
       P2 z[5] = {y[5 * q], y[5 * q + 1], y[5 * q + 2], y[5 * q + 3], y[5 * q + 4]};
-      dft5p(z, pl.W5c, false);
-#pragma unroll
-      for (int k0 = 1; k0 < 5; ++k0) z[k0] = v2::p2_mul(z[k0], UT[r * k0]);
+      dft5p(z, pl.W5c, false);   // (prime-factor form: no twiddle between this stage and the power-of-two part)
 #pragma unroll
       for (int k0 = 0; k0 < 5; ++k0) y[5 * q + k0] = z[k0];
     }
@@ -199,7 +206,7 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k1_cols5(DevPlan pl, const 
     P2* W = reinterpret_cast<P2*>(Wout);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t row = f0 * L + brev_l<J>(f1 + R1 * g2 + 8 * R1 * j);   // column frequency k0 + 5 (k1 + R1 k2 + 8 R1 k3)
+      const uint32_t row = f0 * L + brev_l<J>(f1 + R1 * g2 + 8 * R1 * j);   // slot (k0, kr = k1 + R1 k2 + 8 R1 k3): column frequency PU k0 + PV kr
       W[size_t(row) * pl.M2 + i2] = {gf::mul(x[j].a, ca), gf::mul(x[j].b, ca)};
       if (j < 7) ca = gf::mul(ca, B);
     }
@@ -273,17 +280,14 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const 
   if (t < 512) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const uint32_t r = (t + 512 * q) >> LC;
       P2 w5[5] = {y[5 * q], y[5 * q + 1], y[5 * q + 2], y[5 * q + 3], y[5 * q + 4]};
-#pragma unroll
-      for (int k0i = 1; k0i < 5; ++k0i) { const uint32_t e = r * k0i; w5[k0i] = v2::p2_mul(w5[k0i], UT[e ? M1 - e : 0]); }
       dft5p(w5, pl.W5c, true);
 #pragma unroll
       for (int d0 = 0; d0 < 5; ++d0) y[5 * q + d0] = w5[d0];
     }
   }
-  exchange<10, 8, S::SA>(X, y, x, t < 512, true,
-                  [&](int k) { return 1024u * (k % 5) + t + 512u * (k / 5); },
+  exchange<10, 8, S::SAb>(X, y, x, t < 512, true,
+                  [&](int k) { const uint32_t g = t + 512u * (k / 5); return ((L * (k % 5) + 5 * (g >> LC)) % M1) * C + (g & (C - 1)); },
                   [&](int k) { return (t + kThreads * (uint32_t(k) >> LC)) * C + (uint32_t(k) & (C - 1)); });
   // ---- unweight, x a, carry along the thread's runs ----
   const uint32_t di = pl.DI[size_t(T) * kThreads + t];
@@ -336,17 +340,17 @@ __global__ void __launch_bounds__(kLaunchThreads, 2) k3_cols5(DevPlan pl, const 
   PROBE_END(pl)
 }
 
-// chain starts omega_m^(i2 (k0 + 5 k1 + 5 R1 k2)) TB[2 i2] and ratios omega_m^(40 R1 i2) of the B3 thread map (and inverses with TBi)
+// chain starts omega_m^(i2 (PU k0 + PV (k1 + R1 k2))) TB[2 i2] and ratios omega_m^(PV 8 R1 i2) of the B3 thread map (and inverses with TBi)
 template <int J>
 __global__ void __launch_bounds__(640) k_build_f0(DevPlan pl, uint64_t* __restrict__ f0f, uint64_t* __restrict__ f0i, uint64_t* __restrict__ fbf, uint64_t* __restrict__ fbi) {
   using S = Shape<J>;
   const uint32_t t = threadIdx.x, T = blockIdx.x;
   const uint32_t c = t & (S::C - 1), g2 = (t >> S::LC) & 7, f1 = (t >> (S::LC + 3)) & (S::R1 - 1), f0 = t >> 7, i2 = S::C * T + c;
-  const uint64_t ea = uint64_t(i2) * (f0 + 5 * f1 + 5 * S::R1 * g2);
+  const uint64_t ea = uint64_t(i2) * (S::PU * f0 + S::PV * (f1 + S::R1 * g2)) % pl.m;   // i2 x the slot's frequency label (kernels.hpp col_label)
   f0f[size_t(T) * kThreads + t] = gf::mul(v2::tw_lookup(pl, ea), pl.TB[2 * i2]);
   f0i[size_t(T) * kThreads + t] = gf::mul(v2::tw_lookup(pl, ea ? pl.m - ea : 0), pl.TBi[2 * i2]);
   if (t < S::C) {
-    const uint64_t eb = uint64_t(i2) * (40 * S::R1);
+    const uint64_t eb = uint64_t(i2) * (S::PV * 8 * S::R1) % pl.m;   // the label advances by PV 8 R1 per step of k3
     fbf[i2] = v2::tw_lookup(pl, eb);
     fbi[i2] = v2::tw_lookup(pl, eb ? pl.m - eb : 0);
   }
@@ -354,6 +358,7 @@ __global__ void __launch_bounds__(640) k_build_f0(DevPlan pl, uint64_t* __restri
 }  // namespace v5
 
 static bool v5_j1(const DevPlan& pl) { return pl.M1 == 2560; }
+void v5_pfa(const DevPlan& pl, uint32_t* u, uint32_t* v) { *u = v5_j1(pl) ? v5::Shape<1>::PU : v5::Shape<0>::PU; *v = v5::Shape<0>::PV; }
 size_t v5_threads_per_tile() { return v5::kThreads; }
 hipError_t v5_configure() {
   for (const void* f : {reinterpret_cast<const void*>(v5::k1_cols5<0>), reinterpret_cast<const void*>(v5::k3_cols5<0, false>), reinterpret_cast<const void*>(v5::k3_cols5<0, true>)}) {

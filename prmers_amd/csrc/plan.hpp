@@ -202,7 +202,9 @@ inline Plan make_plan(uint32_t p, const char* spec = nullptr, bool build_tables 
     pl.TBi[x] = gf::inv(pl.TB[x]);
   }
   pl.twh = uint32_t((ilog2(m) + 2) / 2);
-  const size_t lo_n = size_t(1) << pl.twh, hi_n = (m >> pl.twh) + 1;
+  // (TWhi covers exponents below m + 2^20: the row kernels index it with label + M1 k, k < M2, and a frequency label of the prime-factor
+  // columns -- kernels.hpp col_label -- is an unreduced 1536 k0 + 1025 kr < 2^20)
+  const size_t lo_n = size_t(1) << pl.twh, hi_n = ((m + (size_t(1) << 20)) >> pl.twh) + 2;
   pl.TWlo.resize(lo_n); pl.TWhi.resize(hi_n);
   pl.TWlo[0] = 1; for (size_t i = 1; i < lo_n; ++i) pl.TWlo[i] = gf::mul(pl.TWlo[i - 1], om);
   const uint64_t step = gf::mul(pl.TWlo[lo_n - 1], om);

@@ -19,7 +19,10 @@ RG = [list(range(32*g, 32*g+32)) for g in range(2)]
 def pats(J):
     C = 4 >> J; LC = 2 - J; L = 256 << J; R1 = 4 << J
     def A_w(t, k): return (t + 640 * (k // C)) * C + (k % C)
-    def A_r(t, k):
+    def A_r(t, k):   # prime-factor input map: i1 = (L d0 + 5 r) mod M1
+        if t >= 512: return None
+        g = t + 512 * (k // 5); return ((L * (k % 5) + 5 * (g // C)) % (5 * L)) * C + (g % C)
+    def A_o(t, k):   # radix-5 outputs, slot (k0 L + r) C + c
         if t >= 512: return None
         g = t + 512 * (k // 5); return 1024 * (k % 5) + g
     def dec1(t): return t & 1, (t >> 1) & 7, (t >> 4) & 7, t >> 7
@@ -32,7 +35,7 @@ def pats(J):
         c, f3, f1, f0 = dec2(t); return (f0 * L + 64 * f1 + 8 * k + f3) * C + c
     def B3_r(t, k):
         c, g2, f1, f0 = dec2(t); return (f0 * L + 64 * f1 + 8 * g2 + k) * C + c
-    return {"A": (A_w, 8, A_r, 10), "B1": (A_r, 10, B1_r, 8), "B2": (B1_r, 8, B2_r, 8), "B3": (B2_r, 8, B3_r, 8)}
+    return {"A": (A_w, 8, A_r, 10), "B1": (A_o, 10, B1_r, 8), "B2": (B1_r, 8, B2_r, 8), "B3": (B2_r, 8, B3_r, 8)}
 for J in (0, 1):
     print("J =", J)
     for name, (fw, nw, fr, nr) in pats(J).items():
