@@ -48,6 +48,36 @@ def test_plan_policy_of_the_sizes_beyond_rows_of_4096():
     assert resolve_plan(332000003, "m2=8192") == "marin-hip:n=20971520:m1=1280:m2=8192:c=4"   # the round-3 plan stays selectable
 
 
+def test_prime_factor_maps_of_the_radix5_columns():
+    """kernels_v5.hip Shape<J>::PU / PV (read from the source): the Good-Thomas maps of the 5 x L column split -- input i1 = (L d0 + 5 r) mod M1 and
+    output frequency (PU k0 + PV kr) mod M1 are bijections, PU / PV are the CRT idempotents, and with them the length-M1 DFT factors into a
+    DFT-5 and a DFT-L with no twiddle in between (checked numerically over a small prime field for L = 8 with the same construction)."""
+    src = open(os.path.join(ROOT, "prmers_amd", "csrc", "kernels_v5.hip")).read()
+    m = re.search(r"PU = J \? (\d+)u : (\d+)u, PV = (\d+)u", src)
+    pu1, pu0, pv = map(int, m.groups())
+    for L, pu in ((256, pu0), (512, pu1)):
+        M1 = 5 * L
+        assert pu % 5 == 1 and pu % L == 0 and pv % L == 1 and pv % 5 == 0
+        assert sorted((L * d0 + 5 * r) % M1 for d0 in range(5) for r in range(L)) == list(range(M1))
+        assert sorted((pu * k0 + pv * kr) % M1 for k0 in range(5) for kr in range(L)) == list(range(M1))
+        assert pu * 4 + pv * (L - 1) < (1 << 20)          # the unreduced labels stay below the reach of the root table (plan.hpp TWhi)
+    # the factorisation itself, on a toy field: q = 41, N = 40 = 5 x 8, omega of order 40
+    q, N, L = 41, 40, 8
+    w = next(g for g in range(2, q) if pow(g, N, q) == 1 and all(pow(g, N // f, q) != 1 for f in (2, 5)))
+    u, v = pow(L, -1, 5), pow(5, -1, L)
+    PU, PV = L * u, 5 * v
+    x = [(7 * i * i + 3 * i + 1) % q for i in range(N)]
+    X = [sum(x[n] * pow(w, n * k, q) for n in range(N)) % q for k in range(N)]
+    w5, wL = pow(w, N // 5, q), pow(w, 5, q)
+    for k0 in range(5):
+        for kr in range(L):
+            acc = 0
+            for d0 in range(5):
+                for r in range(L):
+                    acc += x[(L * d0 + 5 * r) % N] * pow(w5, d0 * k0, q) * pow(wL, r * kr, q)
+            assert acc % q == X[(PU * k0 + PV * kr) % N]
+
+
 def test_plan_weight_tables_and_digit_info_words():
     """plan.hpp: digit widths, both factorisations of the IBDWT weights (incl. the second half of SA/TA used
     for odd digits), the inverse tables and the 2-bit-per-digit DI words, digit by digit against the defining
