@@ -111,8 +111,13 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
     const std::string sel = ks ? ks : "v2";
     v2rows_ = (sel == "v2" || sel == "v2rows") && v2_rows_supported(dp_);
     v2cols_ = (sel == "v2" || sel == "v2cols") && v2_cols_supported(dp_);
-    dp_.lab_u = 1; dp_.lab_v = pl_.r5;
+    dp_.lab_u = 1; dp_.lab_v = pl_.r5; dp_.lab_red = 0;
     if (v2cols_ && v5_cols_shape(dp_)) v5_pfa(dp_, &dp_.lab_u, &dp_.lab_v);   // radix-5 columns in prime-factor form: their own frequency labels
+    else if (!v2cols_ && pl_.r5 == 5 && !pl_.split5 && pl_.L1 > 1) {   // the generic radix-5 stage in prime-factor form (kernels.hip lds_radix5)
+      uint32_t u = 1; while ((pl_.L1 * u) % 5 != 1) ++u;
+      dp_.lab_u = pl_.L1 * u;   // L1 (L1^-1 mod 5); lab_v stays 5
+      dp_.lab_red = pl_.M1;     // lab_u blk + 5 rq <= 16 L1 + 5 (L1 - 1) < 5 M1: four conditional subtractions
+    }
     if (v2rows_ || v2cols_) HIPCHK(v2_configure());
     if (v2cols_) {   // four-step chain starts and ratios: built once on the device (2 x tiles x 512 + 2 x M2 words)
       const size_t nt = pl_.tiles() * v2_threads_per_tile(dp_);

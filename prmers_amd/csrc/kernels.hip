@@ -230,26 +230,41 @@ __device__ __forceinline__ void dft5(P2 (&x)[5], const uint64_t (&c5)[4]) {
   else          { x[1] = p2_sub(B1, Pp); x[4] = p2_add(B1, Pp); x[2] = p2_sub(B2, Q); x[3] = p2_add(B2, Q); }
 }
 
-// radix-5 stage of the column DFT (first forward / last inverse): 5 blocks of L1, twiddle omega_M1^(t*k)
+// radix-5 stage of the column DFT (first forward / last inverse): 5 blocks of L1.
+// Mixed-radix form (lab_u == 1: the split sweeps, and every plan with L1 = 1): inputs (L1 r + t), twiddle omega_M1^(t k) on output k.
+// Prime-factor form (round 4; 5 and L1 are coprime): inputs i1 = (L1 r + 5 t) mod M1, no twiddle, output k0 in place at L1 k0 + (5 t mod L1) --
+// the same five slots -- so block k0 holds its sequence permuted by t -> 5 t mod L1, the power-of-two transform of that block puts the
+// frequency kr = 5 k mod L1 at output k, and slot (k0, k) holds the column frequency (lab_u k0 + 5 k) mod M1 with lab_u = L1 (L1^-1 mod 5):
+// the frequency label the engine hands to every kernel (kernels.hpp col_label).  Four table products per butterfly and direction fewer.
 template <bool INVERSE>
 __device__ __forceinline__ void lds_radix5(const DevPlan& pl, P2* X, uint32_t ncols, uint32_t tid, uint32_t nthr) {
   const uint32_t L1 = pl.L1, total = L1 * ncols;
+  const bool pfa = pl.lab_u != 1;
   for (uint32_t idx = tid; idx < total; idx += nthr) {
     const uint32_t col = idx & (ncols - 1), t = idx >> pl.logC;   // ncols = C
+    const uint32_t t5 = 5 * t, rho = pfa ? (t5 & (L1 - 1)) : t, w0 = pfa ? (t5 >> pl.logL1) : 0u;   // 5 t = rho + L1 w0: input r sits in block (r + w0) mod 5
     P2 x[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) x[r] = X[(L1 * r + t) * ncols + col];
     if (!INVERSE) {
-      dft5<false>(x, pl.W5c);
 #pragma unroll
-      for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[t * k]);  // t*k < M1
+      for (uint32_t r = 0; r < 5; ++r) { const uint32_t b = r + w0; x[r] = X[(L1 * (b >= 5 ? b - 5 : b) + rho) * ncols + col]; }
+      dft5<false>(x, pl.W5c);
+      if (!pfa) {
+#pragma unroll
+        for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[t * k]);  // t*k < M1
+      }
+#pragma unroll
+      for (int r = 0; r < 5; ++r) X[(L1 * r + rho) * ncols + col] = x[r];
     } else {
 #pragma unroll
-      for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[(t * k) ? pl.M1 - t * k : 0]);
-      dft5<true>(x, pl.W5c);
-    }
+      for (int r = 0; r < 5; ++r) x[r] = X[(L1 * r + rho) * ncols + col];
+      if (!pfa) {
 #pragma unroll
-    for (int r = 0; r < 5; ++r) X[(L1 * r + t) * ncols + col] = x[r];
+        for (int k = 1; k < 5; ++k) x[k] = p2_mul(x[k], pl.UT1[(t * k) ? pl.M1 - t * k : 0]);
+      }
+      dft5<true>(x, pl.W5c);
+#pragma unroll
+      for (uint32_t r = 0; r < 5; ++r) { const uint32_t b = r + w0; X[(L1 * (b >= 5 ? b - 5 : b) + rho) * ncols + col] = x[r]; }
+    }
   }
   __syncthreads();
 }

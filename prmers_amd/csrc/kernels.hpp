@@ -20,6 +20,7 @@ struct DevPlan {
   // set but one; the radix-5 columns in prime-factor form (kernels_v5.hip) hold the frequency (PU k0 + PV kr) mod M1 in slot (k0, kr) and the
   // engine sets (PU, PV) when they run both column sweeps.  See col_label() below.
   uint32_t lab_u, lab_v;
+  uint32_t lab_red;   // the generic prime-factor radix-5 stage (kernels.hip lds_radix5): labels are taken mod M1 (lab_red = M1; they are below 5 M1); 0: as they are
 #if defined(MI355_PROBE)
   uint64_t* probe;        // timeline probe (tools/probe.py, libmi355_engine_probe.so only): 8 words per work-group, or null
   uint32_t probe_mod;     // blockIdx.x is taken modulo this (launches of several rounds over the same tiles)
@@ -33,7 +34,14 @@ struct DevPlan {
 // needs SOME integer congruent to it mod M1, the same one in the front sweep, the row sweep and the back sweep: a representative k1 + M1 s
 // shifts the row transform's outputs by s places and the total frequency k1 + M1 k2 stays what the label says.  The prime-factor columns use
 // PU blk + PV rq unreduced (< 2^20; their twiddle chains step through rq by constant ratios); the two-level root table reaches m + 2^20.
-__device__ __forceinline__ uint32_t col_label(const DevPlan& pl, uint32_t blk, uint32_t rq) { return pl.lab_u * blk + pl.lab_v * rq; }
+__device__ __forceinline__ uint32_t col_label(const DevPlan& pl, uint32_t blk, uint32_t rq) {
+  uint32_t l = pl.lab_u * blk + pl.lab_v * rq;
+  if (pl.lab_red) {   // the generic kernels multiply a label by a column index and need the product below m: the representative below M1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l = (l >= pl.lab_red) ? l - pl.lab_red : l;
+  }
+  return l;
+}
 // exponent of rho = omega_m^(label + M1 k): below m + 2^20 (plan.hpp TWhi)
 __device__ __forceinline__ uint64_t rho_exponent(const DevPlan& pl, uint32_t label, uint64_t k) { return uint64_t(label) + uint64_t(pl.M1) * k; }
 #endif
