@@ -47,7 +47,10 @@ def test_device_canonical_form_matches_host_and_bigint(p, plan):
         with host_carry():
             h = Engine(p, 4, plan=plan)
         try:
-            for v in special_values(p, rng):
+            vals = special_values(p, rng)
+            if p > 2000000:   # (Python's big-integer squarings of 3 M bits dominate the suite otherwise: 105 s of its 400)
+                vals = [vals[i] for i in (0, 3, 4, 6, 9, 12, 13)]
+            for v in vals:
                 e.set_int(0, v); h.set_int(0, v)
                 assert e.get_int(0) == v % Mp == h.get_int(0)
                 assert np.array_equal(e.digits(0), h.digits(0))
