@@ -118,6 +118,11 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
       dp_.lab_u = pl_.L1 * u;   // L1 (L1^-1 mod 5); lab_v stays 5
       dp_.lab_red = pl_.M1;     // lab_u blk + 5 rq <= 16 L1 + 5 (L1 - 1) < 5 M1: four conditional subtractions
     }
+    {   // every exponent label + M1 k, k < M2, that a row kernel looks up lies inside the two-level root table (plan.hpp TWhi)
+      const uint64_t max_label = dp_.lab_red ? uint64_t(pl_.M1) - 1 : uint64_t(dp_.lab_u) * (pl_.r5 - 1) + uint64_t(dp_.lab_v) * (pl_.L1 - 1);
+      if (max_label + uint64_t(pl_.M1) * (pl_.M2 - 1) >= (uint64_t(pl_.TWhi.size()) << pl_.twh))
+        throw std::runtime_error("internal: column frequency labels beyond the root table");
+    }
     if (v2rows_ || v2cols_) HIPCHK(v2_configure());
     if (v2cols_) {   // four-step chain starts and ratios: built once on the device (2 x tiles x 512 + 2 x M2 words)
       const size_t nt = pl_.tiles() * v2_threads_per_tile(dp_);
