@@ -89,6 +89,27 @@ def test_plan_weight_tables_and_digit_info_words():
     assert "m1=1280:m2=8:c=4 digits=20480 di_checked=20480" in out and "m1=2560:m2=8:c=2 digits=40960 di_checked=40960" in out   # radix-5 columns
 
 
+def test_product_library_has_no_experimental_code_and_the_experiments_still_build():
+    """The experiments that did not make the product (cooperative one-launch squaring, back + front in one launch) live behind
+    -DMI355_EXPERIMENTAL: the product library exports and contains nothing of them, and their sources still compile for gfx950 (host and device passes, -fsyntax-only; `make -C prmers_amd/csrc exp` builds the library)
+    (their parity checks run on a GPU box: tools/exp_coop_check.py)."""
+    from prmers_amd import engine as E
+    if not os.path.exists(E.LIB_PATH):
+        pytest.skip("libmi355_engine.so not built")
+    syms = subprocess.run(["nm", "-D", "--defined-only", E.LIB_PATH], capture_output=True, text=True).stdout.lower()
+    assert "coop" not in syms and "chain" not in syms and "k31" not in syms
+    blob = open(E.LIB_PATH, "rb").read()
+    for name in (b"k_coop", b"k31_cols", b"MI355_COOP", b"MI355_CHAIN"):
+        assert name not in blob, name
+    csrc = os.path.join(ROOT, "prmers_amd", "csrc")
+    procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-DMI355_EXPERIMENTAL", "-fsyntax-only", "-Wno-unused-command-line-argument",
+                               os.path.join(csrc, f)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for f in ("kernels.hip", "kernels_v2.hip", "kernels_v3.hip", "engine.hip")]
+    for pr in procs:
+        out, _ = pr.communicate()
+        assert pr.returncode == 0, out[-2000:]
+
+
 def test_c_abi_exports_and_no_gpu_behaviour():
     """the library loads, exports every symbol the header declares, resolves plans without a GPU and
     refuses to create an engine without one (no CPU fallback)."""
