@@ -76,6 +76,17 @@ def test_prime_factor_maps_of_the_radix5_columns():
                 for r in range(L):
                     acc += x[(L * d0 + 5 * r) % N] * pow(w5, d0 * k0, q) * pow(wL, r * kr, q)
             assert acc % q == X[(PU * k0 + PV * kr) % N]
+    # the in-place form of the generic kernels (kernels.hip lds_radix5): output k0 of group t goes to slot L k0 + (5 t mod L), the block transform
+    # then leaves the frequency (lab_u k0 + 5 k) mod N in slot (k0, k), lab_u = L (L^-1 mod 5) -- engine.hip sets exactly that
+    slots = [0] * N
+    for t in range(L):
+        for k0 in range(5):
+            slots[L * k0 + (5 * t) % L] = sum(x[(L * d0 + 5 * t) % N] * pow(w5, d0 * k0, q) for d0 in range(5)) % q
+    lab_u = L * u
+    for k0 in range(5):
+        for k in range(L):
+            z = sum(slots[L * k0 + rho] * pow(wL, rho * k, q) for rho in range(L)) % q
+            assert z == X[(lab_u * k0 + 5 * k) % N]
 
 
 def test_plan_weight_tables_and_digit_info_words():
