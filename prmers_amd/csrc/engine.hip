@@ -50,7 +50,9 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
 
   // one allocation for all tables
   auto padded = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
-  const size_t total = padded(pl_.SA.size() * 4) + padded(pl_.SB.size() * 4) + padded(pl_.TA.size() * 8) * 2 +
+  std::vector<uint64_t> tah(pl_.TA.size()), tai2(pl_.TAi.size());
+  for (size_t i = 0; i < tah.size(); ++i) { tah[i] = gf::half(pl_.TA[i]); tai2[i] = gf::dbl(pl_.TAi[i]); }
+  const size_t total = padded(pl_.SA.size() * 4) + padded(pl_.SB.size() * 4) + padded(pl_.TA.size() * 8) * 4 +
                        padded(pl_.TB.size() * 8) * 2 + padded(pl_.TWlo.size() * 8) + padded(pl_.TWhi.size() * 8) +
                        padded(pl_.UT1.size() * 8) + padded(pl_.UT2.size() * 8) + padded(pl_.S2r.size() * 8) * 2 +
                        padded(pl_.S1r.size() * 8) * 2 + 1024;
@@ -62,6 +64,8 @@ Engine::Engine(uint32_t p, size_t reg_count, int device, bool verbose, const cha
   dp_.SB = upload(cur, base, pl_.SB, host);
   dp_.TA = upload(cur, base, pl_.TA, host);
   dp_.TAi = upload(cur, base, pl_.TAi, host);
+  dp_.TAh = upload(cur, base, tah, host);
+  dp_.TAi2 = upload(cur, base, tai2, host);
   dp_.TB = upload(cur, base, pl_.TB, host);
   dp_.TBi = upload(cur, base, pl_.TBi, host);
   dp_.TWlo = upload(cur, base, pl_.TWlo, host);

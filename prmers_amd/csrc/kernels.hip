@@ -322,8 +322,8 @@ __device__ __forceinline__ void front_body(const DevPlan& pl, const uint32_t* di
     const uint32_t sb = pl.SB[2 * i2];
     digit_info(pl, sa, sb, w0, wr0);
     digit_info(pl, pl.SA[M1 + i1], sb, w1, wr1);
-    uint64_t a0 = gf::mul_u32(gf::half(pl.TA[i1]), d.x << (wr0 ? 0 : 1));
-    const uint64_t a1 = gf::mul_u32(gf::half(pl.TA[M1 + i1]), d.y << (wr1 ? 0 : 1));
+    uint64_t a0 = gf::mul_u32(pl.TAh[i1], d.x << (wr0 ? 0 : 1));
+    const uint64_t a1 = gf::mul_u32(pl.TAh[M1 + i1], d.y << (wr1 ? 0 : 1));
     if (sub && (T | e) == 0) a0 = gf::sub(a0, uint64_t(sub));
     X[e] = {a0, a1};
   }
@@ -455,7 +455,7 @@ __device__ __forceinline__ void back_body(const DevPlan& pl, const uint64_t* Win
   for (uint32_t i1 = tid; i1 < M1; i1 += nthr) {
     const uint32_t sa[2] = {pl.SA[i1], pl.SA[M1 + i1]};          // even / odd digit (second half: see k_front)
     const uint64_t tai[2] = {pl.TAi[i1], pl.TAi[M1 + i1]};
-    const uint64_t tai2[2] = {gf::dbl(tai[0]), gf::dbl(tai[1])};  // wrapped exponents: the weight was halved
+    const uint64_t tai2[2] = {pl.TAi2[i1], pl.TAi2[M1 + i1]};  // wrapped exponents: the weight was halved
     uint64_t carry = 0;
     uint32_t addh[4] = {0, 0, 0, 0};   // first digits of the addend's run with its pending carry folded in (C >= 2)
     const uint2* ad = nullptr;
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(256) k_front_split_a(DevPlan pl, const uint32_
     uint32_t w0, w1; bool wr0, wr1;
     digit_info(pl, pl.SA[i1], sb, w0, wr0);
     digit_info(pl, pl.SA[M1 + i1], sb, w1, wr1);
-    x[r] = {gf::mul_u32(gf::half(pl.TA[i1]), d.x << (wr0 ? 0 : 1)), gf::mul_u32(gf::half(pl.TA[M1 + i1]), d.y << (wr1 ? 0 : 1))};   // see k_front
+    x[r] = {gf::mul_u32(pl.TAh[i1], d.x << (wr0 ? 0 : 1)), gf::mul_u32(pl.TAh[M1 + i1], d.y << (wr1 ? 0 : 1))};   // see k_front
   }
   dft5<false>(x, pl.W5c);
 #pragma unroll
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(256) k_back_split_a(DevPlan pl, const uint64_t
     for (int b = 0; b < 2; ++b) {
       uint32_t width; bool wrap;
       digit_info(pl, sa[b], sb, width, wrap);
-      const uint64_t u = gf::mul(b ? x[r].b : x[r].a, wrap ? gf::dbl(tai[b]) : tai[b]);
+      const uint64_t u = gf::mul(b ? x[r].b : x[r].a, wrap ? pl.TAi2[b ? M1 + i1 : i1] : tai[b]);
       const uint64_t mask = (uint64_t(1) << width) - 1;
       const uint64_t dlo = u & mask, chi = u >> width;      // adc_mul (marin.cl:194-201)
       const uint64_t rr = dlo * a + carry;

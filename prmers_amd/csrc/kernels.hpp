@@ -9,6 +9,7 @@ struct DevPlan {
   uint32_t n, m, M1, M2, L1, logL1, logM2, r5, C, logC, q, t, twh;
   const uint32_t *SA, *SB;
   const uint64_t *TA, *TAi, *TB, *TBi;
+  const uint64_t *TAh, *TAi2;   // TA / 2 and 2 TAi, entry by entry: what the sweeps multiply with when the exponent split wraps (no per-thread half / double)
   const uint64_t *TWlo, *TWhi, *UT1, *UT2;
   const uint64_t *S2r, *S2ri, *S1r, *S1ri;   // seam tables of the radix-8 kernels (null when the shape is not served)
   uint64_t I4, I4inv;

@@ -508,7 +508,7 @@ __device__ __forceinline__ void front_tile(const DevPlan& pl, P2* X, uint32_t T,
   for (int d1 = 0; d1 < R; ++d1) {
     const uint32_t i1 = 512 * d1 + t;
     // odd digits: exponent split SA[M1 + i1] + SB[2 i2] (plan.hpp), hence their own TA entry
-    const uint64_t tah = gf::half(pl.TA[i1]), tah1 = gf::half(pl.TA[S::M1 + i1]);
+    const uint64_t tah = pl.TAh[i1], tah1 = pl.TAh[S::M1 + i1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       // weight TA*TB, halved when the exponents wrap: the halving is moved onto TA (once per run) and
@@ -625,9 +625,14 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
   dft8p<true>(x);
   // unweighting tables of the carry phase (thread (d2|d3|d4): runs i1 = 512 d1 + t), requested one exchange early;
   // odd digits take theirs from the second half of SA / TAi
-  uint64_t btai_e[R], btai_o[R];
+  // (the doubled entries too, from their own table -- except with four runs a thread, where 16 more registers across the exchange would spill)
+  constexpr bool PRE2 = (R <= 2);
+  uint64_t btai_e[R], btai_o[R], btai2_e[R], btai2_o[R];
 #pragma unroll
-  for (int d1 = 0; d1 < R; ++d1) { btai_e[d1] = pl.TAi[512 * d1 + t]; btai_o[d1] = pl.TAi[S::M1 + 512 * d1 + t]; }
+  for (int d1 = 0; d1 < R; ++d1) {
+    btai_e[d1] = pl.TAi[512 * d1 + t]; btai_o[d1] = pl.TAi[S::M1 + 512 * d1 + t];
+    if (PRE2) { btai2_e[d1] = pl.TAi2[512 * d1 + t]; btai2_o[d1] = pl.TAi2[S::M1 + 512 * d1 + t]; }
+  }
   EXCH_STRIDED_TO_THREAD_MAJOR(X, x, t)
 #define MI355_CALL(W) stage_r_inv_const<R, W>(x)
   MI355_SWITCH8(wave, MI355_CALL)
@@ -635,7 +640,7 @@ __device__ __forceinline__ void back_tile(const DevPlan& pl, P2* X, uint32_t T, 
 #pragma unroll
   for (int d1 = 0; d1 < R; ++d1) {
     const uint64_t tai_e = btai_e[d1], tai_o = btai_o[d1];
-    const uint64_t tai2_e = gf::dbl(tai_e), tai2_o = gf::dbl(tai_o);
+    const uint64_t tai2_e = PRE2 ? btai2_e[d1] : gf::dbl(tai_e), tai2_o = PRE2 ? btai2_o[d1] : gf::dbl(tai_o);
     uint64_t carry = carry0[d1];
 #pragma unroll
     for (int k = 0; k < S::ND; ++k) {

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(kThreads) k1_cols256(DevPlan pl, const uint32_
   const uint32_t c4 = t & 3u, kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t), i2 = 4 * T + c4;
   const uint64_t fca0 = pl.F0f[size_t(T) * kThreads + t], fB = pl.FBf[i2];   // chain start omega_m^(i2 kb) TB[2 i2], ratio omega_m^(64 i2)
   const uint32_t di = pl.DI[size_t(T) * kThreads + t];
-  const uint64_t tah = gf::half(pl.TA[t]), tah1 = gf::half(pl.TA[256 + t]);   // odd digits: exponent split SA[M1 + i1] + SB[2 i2] (plan.hpp)
+  const uint64_t tah = pl.TAh[t], tah1 = pl.TAh[256 + t];   // odd digits: exponent split SA[M1 + i1] + SB[2 i2] (plan.hpp)
   uint32_t dg[8];
   {
     const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * 256 + t) * 2;
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(kThreads) k3_cols256(DevPlan pl, const uint64_
 #undef WI
 #undef RI
   // unweight, x a, carry along the thread's run (i1 = t)
-  const uint64_t tai2_e = gf::dbl(tai_e), tai2_o = gf::dbl(tai_o);
+  const uint64_t tai2_e = pl.TAi2[t], tai2_o = pl.TAi2[256 + t];
   uint64_t carry = 0;
   uint32_t dg[8];
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(2 * kThreads) k1_cols256_planes(DevPlan pl, co
   const uint32_t c4 = t & 3u, kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t), i2 = 4 * T + c4;
   const uint64_t fca0 = pl.F0f[size_t(T) * kThreads + t], fB = pl.FBf[i2];
   const uint32_t di = pl.DI[size_t(T) * kThreads + t];
-  const uint64_t tah = gf::half(pl.TA[256 * pln + t]);   // odd digits: the second half of TA (plan.hpp)
+  const uint64_t tah = pl.TAh[256 * pln + t];   // odd digits: the second half of TA (plan.hpp)
   uint32_t dg[8];
   {
     const uint4* src = reinterpret_cast<const uint4*>(digits) + (size_t(T) * 256 + t) * 2;
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(2 * kThreads) k3_cols256_planes(DevPlan pl, co
 #undef WI
 #undef RI
   // unweight this lane's plane (digit 2 c + plane of the run i1 = t), then both lanes take the partner's four values and run the carry
-  const uint64_t tai2 = gf::dbl(tai);
+  const uint64_t tai2 = pl.TAi2[256 * pln + t];
   uint64_t own[4], oth[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -702,7 +702,7 @@ __global__ void __launch_bounds__(2 * kThreads) k31_cols256_planes(DevPlan pl, u
   }
   const uint32_t c4 = t & 3u, kb = hi2(t) + 4 * d2nd(t) + 16 * d3rd(t), i2 = 4 * T + c4;
   const uint32_t di = pl.DI[size_t(T) * kThreads + t];
-  const uint64_t tai = pl.TAi[256 * pln + t], tah = gf::half(pl.TA[256 * pln + t]);
+  const uint64_t tai = pl.TAi[256 * pln + t], tah = pl.TAh[256 * pln + t];
   const uint64_t fca0 = pl.F0f[size_t(T) * kThreads + t], fB = pl.FBf[i2];
   const uint32_t row0 = __brev(kb) >> 24;
   // ---- back sweep of the tile (k3_cols256_planes) ----
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(2 * kThreads) k31_cols256_planes(DevPlan pl, u
   V3_EXCHW(X, x, pln, WI, RI)
 #undef WI
 #undef RI
-  const uint64_t tai2 = gf::dbl(tai);
+  const uint64_t tai2 = pl.TAi2[256 * pln + t];
   uint64_t own[4], oth[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
